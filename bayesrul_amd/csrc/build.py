@@ -1,0 +1,36 @@
+"""Builds libbayesrul_amd.so (the C-ABI library of include/bayesrul_amd.h) for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the dev container; the built .so is
+git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libbayesrul_amd.so")
+SOURCES = ["plan.hip"]
+HEADERS = ["common.h", "desc.h", "kernels_core.h", "kernels_group.h", "kernels_misc.h",
+           os.path.join("..", "..", "include", "bayesrul_amd.h")]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, cwd=HERE, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,512 @@
+// Parameter-side and elementwise kernels: noise generation, weight sampling + KL, head / NLL,
+// gradient chain rule to (mu, rho), ClippedAdam, max-pool backward, predictive aggregation.
+#pragma once
+#include "kernels_core.h"
+
+struct SiteDesc {
+  long off;      // offset in the flat (mu, rho) buffers
+  long numel;
+  int layer;
+  int is_bias;
+};
+
+struct ParamTable {
+  int n_sites;
+  int n_layers;
+  long P;
+  SiteDesc site[BNN_MAX_SITES];
+};
+
+__device__ __forceinline__ int find_site(const ParamTable& T, long e) {
+  int s = 0;
+#pragma unroll 1
+  for (int k = 1; k < T.n_sites; ++k)
+    if (e >= T.site[k].off) s = k;
+  return s;
+}
+
+__device__ __forceinline__ int map_cin(const LayerDesc& L, int ci) {
+  if (L.cmap == CM_BLOCK) return (ci / L.cmap_a) * L.cmap_b + (ci % L.cmap_a);
+  if (L.cmap == CM_FLATTEN) return (ci % L.cmap_b) * L.cmap_a + (ci / L.cmap_b);  // c*L + l -> l*C + c
+  return ci;
+}
+
+// canonical weight element -> (n, forward-image index, transposed-image index)
+__device__ __forceinline__ void map_weight(const LayerDesc& L, long e, int& n, long& fi, long& ti) {
+  const int per_n = L.cin * L.taps;
+  n = (int)(e / per_n);
+  const int rem = (int)(e - (long)n * per_n);
+  const int ci = rem / L.taps;
+  const int t = rem - ci * L.taps;
+  const int cimg = map_cin(L, ci);
+  fi = (long)n * L.KP + (long)t * L.cin_img + cimg;
+  ti = (long)cimg * L.KPt + (long)(L.taps - 1 - t) * L.cout_p8 + n;
+}
+
+// ------------------------------------------------------------------------------------------
+// noise generation (Philox) — the same streams bnn_export_noise writes out
+// ------------------------------------------------------------------------------------------
+__global__ void gen_eps_w_kernel(float* eps, long P, int S, uint64_t seed, uint32_t step) {
+  const long n4 = (P + 3) >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n4 * S) return;
+  const int s = (int)(idx / n4);
+  const long q = idx - (long)s * n4;
+  const f32x4 z = philox_normal4((uint32_t)q, (uint32_t)s, NK_EPSW, step, seed);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (q * 4 + r < P) eps[(long)s * P + q * 4 + r] = z[r];
+}
+
+__global__ void gen_radial_r_kernel(float* rr, int n_sites, int S, uint64_t seed, uint32_t step) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_sites * S) return;
+  const int s = idx / n_sites, site = idx - s * n_sites;
+  const f32x4 z = philox_normal4((uint32_t)site, (uint32_t)s, NK_RADIAL_R, step, seed);
+  rr[idx] = z[0];
+}
+
+// packed sign words for one layer: [S*B examples][words]; example index is global (DP-invariant)
+__global__ void gen_signs_kernel(uint32_t* dst, int words, int S, int B, int Bglob, int goff, int layer, uint32_t kind,
+                                 uint64_t seed, uint32_t step) {
+  const int w4 = (words + 3) >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)S * B * w4) return;
+  const int q = (int)(idx % w4);
+  const long ex = idx / w4;
+  const int s = (int)(ex / B), b = (int)(ex - (long)s * B);
+  const uint32_t gex = (uint32_t)(goff + b);
+  const uint4 u = philox4x32_10(gex * (uint32_t)w4 + (uint32_t)q, (uint32_t)s, kind | ((uint32_t)layer << 8), step,
+                                (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t v[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (q * 4 + r < words) dst[ex * words + q * 4 + r] = v[r];
+}
+
+// floats (+1/-1) [rows][C] -> packed bits (1 = negative)
+__global__ void pack_signs_kernel(const float* src, uint32_t* dst, long rows, int C, int words) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * words) return;
+  const long r = idx / words;
+  const int w = (int)(idx - r * words);
+  uint32_t bits = 0;
+  for (int k = 0; k < 32; ++k) {
+    const int c = w * 32 + k;
+    if (c < C && src[r * C + c] < 0.f) bits |= (1u << k);
+  }
+  dst[idx] = bits;
+}
+
+__global__ void unpack_signs_kernel(const uint32_t* src, float* dst, long rows, int C, int words) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * C) return;
+  const long r = idx / C;
+  const int c = (int)(idx - r * C);
+  dst[idx] = ((src[r * words + (c >> 5)] >> (c & 31)) & 1u) ? -1.f : 1.f;
+}
+
+// LRT eps of one layer, written in the injected layout [rows][cout]
+__global__ void export_lrt_eps_kernel(float* dst, long rows, int cout, int cout_p16, int Lrows, CallGeom cg, int layer,
+                                      uint64_t seed, uint32_t step) {
+  const int c4n = (cout + 3) >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * c4n) return;
+  const long R = idx / c4n;
+  const int c4 = (int)(idx - R * c4n);
+  const long Rg = global_row(cg, Lrows, (int)R);
+  const uint64_t gi = (uint64_t)Rg * (uint64_t)(cout_p16 >> 2) + (uint64_t)c4;
+  const f32x4 z = philox_normal4((uint32_t)gi, (uint32_t)(gi >> 32), NK_LRT | ((uint32_t)layer << 8), step, seed);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (c4 * 4 + r < cout) dst[R * cout + c4 * 4 + r] = z[r];
+}
+
+// ------------------------------------------------------------------------------------------
+// radial: per (particle, site) L2 norm of eps  (guides/radial.py:38)
+// ------------------------------------------------------------------------------------------
+__global__ void site_norm_kernel(const float* eps_w, long P, ParamTable T, float* norms) {
+  const int site = blockIdx.x % T.n_sites, s = blockIdx.x / T.n_sites;
+  const float* e = eps_w + (long)s * P + T.site[site].off;
+  double acc = 0.0;
+  for (long k = threadIdx.x; k < T.site[site].numel; k += blockDim.x) acc += (double)e[k] * (double)e[k];
+  __shared__ double red[4];
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k];
+    norms[s * T.n_sites + site] = (float)sqrt(t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight sampling + image construction + KL / (log q - log p)
+// ------------------------------------------------------------------------------------------
+struct PrepArgs {
+  ParamTable T;
+  const LayerDesc* layers;
+  const float* mu;
+  const float* rho;
+  const float* eps_w;   // [S][P]
+  const float* rad_r;   // [S][n_sites]
+  const float* norms;   // [S][n_sites]
+  int mode;             // BNN_MODE_* (0 normal, 1 lrt, 2 flipout, 3 radial)
+  int S;
+  int want_t;           // build transposed images
+  void* a_hi; void* a_lo; void* b; void* at; void* bt;
+  long slot_stride;     // elements between particles (fwd images)
+  long slott_stride;
+  float* bias_a; float* bias_b;
+  int bias_total;
+  double* kl_acc;       // [S] (radial) or [1]
+  float prior_loc, prior_scale;
+};
+
+template <class P>
+__device__ __forceinline__ void put_img(void* hi, void* lo, long idx, float v) {
+  if constexpr (!P::BF) {
+    ((float*)hi)[idx] = v;
+  } else {
+    const u16 h = f2bf(v);
+    ((u16*)hi)[idx] = h;
+    if (lo) ((u16*)lo)[idx] = f2bf(v - bf2f(h));
+  }
+}
+
+template <class P>
+__global__ void prep_weights_kernel(const PrepArgs A) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = e < A.T.P;
+  const int lane = threadIdx.x & 63;
+  __shared__ double red[8];
+  const int radial = (A.mode == 3);
+  double kl_local = 0.0;  // mean-field KL contribution of this element
+  int si = 0, n = 0, is_bias = 0, bias_idx = 0;
+  long fi = 0, ti = 0;
+  float mu = 0.f, rho = 0.f, sigma = 1.f;
+  if (live) {
+    si = find_site(A.T, e);
+    const SiteDesc sd = A.T.site[si];
+    const LayerDesc& ly = A.layers[sd.layer];
+    const long le = e - sd.off;
+    is_bias = sd.is_bias;
+    mu = A.mu[e];
+    rho = A.rho[e];
+    sigma = expf(rho);
+    n = (int)le;
+    if (!is_bias) map_weight(ly, le, n, fi, ti);
+    fi += ly.w_off;
+    ti += ly.wt_off;
+    bias_idx = ly.bias_off + n;
+    if (!radial) {
+      const float vr = (sigma / A.prior_scale) * (sigma / A.prior_scale);
+      const float t1 = ((mu - A.prior_loc) / A.prior_scale) * ((mu - A.prior_loc) / A.prior_scale);
+      kl_local = 0.5 * ((double)vr + (double)t1 - 1.0 - (double)logf(vr));
+    }
+    if (A.mode == 1) {  // LRT: shared (mu, sigma^2)
+      if (is_bias) {
+        A.bias_a[bias_idx] = mu;
+        A.bias_b[bias_idx] = sigma * sigma;
+      } else {
+        put_img<P>(A.a_hi, A.a_lo, fi, mu);
+        put_img<P>(A.b, nullptr, fi, sigma * sigma);
+        if (A.want_t) {
+          put_img<P>(A.at, nullptr, ti, mu);
+          put_img<P>(A.bt, nullptr, ti, sigma * sigma);
+        }
+      }
+    } else if (A.mode == 2 && !is_bias) {  // flipout: shared mean image
+      put_img<P>(A.a_hi, A.a_lo, fi, mu);
+      if (A.want_t) put_img<P>(A.at, nullptr, ti, mu);
+    }
+  }
+  if (A.mode != 1) {
+    for (int s = 0; s < A.S; ++s) {
+      double term = 0.0;
+      if (live) {
+        float eps = A.eps_w[(long)s * A.T.P + e];
+        if (radial) eps = eps * (A.rad_r[s * A.T.n_sites + si] / A.norms[s * A.T.n_sites + si]);
+        const float dw = sigma * eps;
+        const float w = mu + dw;
+        if (is_bias) {
+          A.bias_a[(long)s * A.bias_total + bias_idx] = w;
+        } else if (A.mode == 2) {
+          put_img<P>(A.b, nullptr, A.slot_stride * s + fi, dw);
+          if (A.want_t) put_img<P>(A.bt, nullptr, A.slott_stride * s + ti, dw);
+        } else {
+          put_img<P>(A.a_hi, A.a_lo, A.slot_stride * s + fi, w);
+          if (A.want_t) put_img<P>(A.at, nullptr, A.slott_stride * s + ti, w);
+        }
+        if (radial) {
+          // log q(w) - log p(w), Normal.log_prob of the radial sample (A6)
+          const float zp = (w - A.prior_loc) / A.prior_scale;
+          term = -0.5 * (double)eps * (double)eps - (double)rho + 0.5 * (double)zp * (double)zp +
+                 (double)logf(A.prior_scale);
+        }
+      }
+      if (radial) {  // all lanes of the wave take part in the reduction
+        const double t = wave_sum_d(term);
+        if (lane == 0) atomicAdd(A.kl_acc + s, t);
+      }
+    }
+  }
+  if (!radial) {
+    const double t = wave_sum_d(kl_local);
+    if (lane == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tt = 0;
+      for (int k = 0; k < (int)(blockDim.x >> 6); ++k) tt += red[k];
+      atomicAdd(A.kl_acc, tt);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// head: softplus -> Threshold(1e-9) on both outputs, likelihood softplus on the scale,
+// Gaussian log-lik and d(-ll)/dz  (A11)
+// ------------------------------------------------------------------------------------------
+struct HeadArgs {
+  const float* z;   // [S*B][2]
+  const float* y;   // [B]
+  float* dz;        // [S*B][2] or null
+  float* preds;     // [S*B][2] or null
+  double* ll_acc;   // [S]
+  int S, B;
+  int with_obs;
+};
+
+__global__ void head_nll_kernel(const HeadArgs A) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  double ll = 0.0;
+  if (idx < A.B) {
+    const long r = (long)s * A.B + idx;
+    const float z0 = A.z[r * 2], z1 = A.z[r * 2 + 1];
+    const float sp0 = softplus_t(z0), sp1 = softplus_t(z1);
+    const bool p0 = sp0 > 1e-9f, p1 = sp1 > 1e-9f;
+    const float o0 = p0 ? sp0 : 1e-9f, o1 = p1 ? sp1 : 1e-9f;
+    if (A.preds) {
+      A.preds[r * 2] = o0;
+      A.preds[r * 2 + 1] = o1;
+    }
+    if (A.with_obs) {
+      const float sc = softplus_t(o1);
+      const float d = A.y[idx] - o0;
+      ll = -(double)(d * d) / (2.0 * (double)sc * (double)sc) - (double)logf(sc) - 0.9189385332046727;
+      if (A.dz) {
+        // d(-ll)/d o0 = -(y - o0)/s^2 ; d(-ll)/d s = -(y-o0)^2/s^3 + 1/s
+        const float g0 = -d / (sc * sc);
+        const float gs = -(d * d) / (sc * sc * sc) + 1.f / sc;
+        const float g1 = gs * dsoftplus_t(o1);
+        A.dz[r * 2] = p0 ? g0 * dsoftplus_t(z0) : 0.f;
+        A.dz[r * 2 + 1] = p1 ? g1 * dsoftplus_t(z1) : 0.f;
+      }
+    } else if (A.dz) {
+      A.dz[r * 2] = 0.f;
+      A.dz[r * 2 + 1] = 0.f;
+    }
+  }
+  __shared__ double red[4];
+  ll = wave_sum_d(ll);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ll;
+  __syncthreads();
+  if (threadIdx.x == 0 && A.with_obs) {
+    double t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k];
+    atomicAdd(A.ll_acc + s, t);
+  }
+}
+
+// loss = (1/S) sum_s [ c*KL_s - c*(N/B)*ll_s ]   (A5 / A6); written to out + grad[2P], grad[2P+1]
+struct LossArgs {
+  const double* kl_acc;
+  const double* ll_acc;
+  int S;
+  int radial;
+  double c, n_over_b;
+  float* loss; float* kl; float* ll;
+  float* grad_tail;  // &grad[2P] or null
+};
+
+__global__ void finish_loss_kernel(const LossArgs A) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double kl = 0, ll = 0;
+  for (int s = 0; s < A.S; ++s) {
+    kl += A.radial ? A.kl_acc[s] : A.kl_acc[0];
+    ll += A.ll_acc[s];
+  }
+  kl /= A.S;
+  ll /= A.S;
+  const double loss = A.c * kl - A.c * A.n_over_b * ll;
+  if (A.loss) *A.loss = (float)loss;
+  if (A.kl) *A.kl = (float)kl;
+  if (A.ll) *A.ll = (float)ll;
+  if (A.grad_tail) {
+    A.grad_tail[0] = (float)loss;
+    A.grad_tail[1] = (float)kl;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// chain rule: weight-image gradients -> d loss / d (mu, rho)   (+ KL / prior terms)
+//   G = d(-sum_b ll_b)/dW per particle (unscaled); scale_ll = c*(N/B)/S
+// ------------------------------------------------------------------------------------------
+struct FinalizeArgs {
+  ParamTable T;
+  const LayerDesc* layers;
+  const float* mu; const float* rho;
+  const float* eps_w; const float* rad_r; const float* norms;
+  const float* gw_a; const float* gw_b; const float* gb_a; const float* gb_b;
+  long gw_stride; int gb_stride;
+  int mode, S;
+  float scale_ll;   // c * (N/B) / S   (0 when with_obs == 0)
+  float c;          // KL scale
+  float prior_loc, prior_scale;
+  float* grad;      // [2P]
+};
+
+__global__ void grad_finalize_kernel(const FinalizeArgs A) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= A.T.P) return;
+  const int si = find_site(A.T, e);
+  const SiteDesc sd = A.T.site[si];
+  const LayerDesc& ly = A.layers[sd.layer];
+  const long le = e - sd.off;
+  const float mu = A.mu[e], rho = A.rho[e];
+  const float sigma = expf(rho);
+  int n = (int)le;
+  long fi = 0, ti = 0;
+  if (!sd.is_bias) map_weight(ly, le, n, fi, ti);
+  const long gi = sd.is_bias ? (long)(ly.bias_off + n) : (ly.w_off + fi);
+  const float* ga = sd.is_bias ? A.gb_a : A.gw_a;
+  const float* gb = sd.is_bias ? A.gb_b : A.gw_b;
+  const long gs = sd.is_bias ? (long)A.gb_stride : A.gw_stride;
+  const float inv_s0sq = 1.f / (A.prior_scale * A.prior_scale);
+  float dmu = 0.f, drho = 0.f;
+  if (A.mode == 1) {  // LRT
+    float sa = 0.f, sb = 0.f;
+    for (int s = 0; s < A.S; ++s) {
+      sa += ga[gs * s + gi];
+      sb += gb[gs * s + gi];
+    }
+    dmu = A.scale_ll * sa;
+    drho = A.scale_ll * sb * 2.f * sigma * sigma;
+  } else if (A.mode == 2) {  // flipout: mean path shared, perturbation dW_s = sigma*eps_s
+    float sa = 0.f, sb = 0.f;
+    for (int s = 0; s < A.S; ++s) {
+      const float eps = A.eps_w[(long)s * A.T.P + e];
+      const float a = ga[gs * s + gi];
+      sa += a;
+      // bias: b_s = mu_b + sigma_b*eps, its gradient arrives through slot A
+      sb += (sd.is_bias ? a : gb[gs * s + gi]) * eps;
+    }
+    dmu = A.scale_ll * sa;
+    drho = A.scale_ll * sb * sigma;
+  } else if (A.mode == 0) {  // plain normal sampling
+    float sa = 0.f, sb = 0.f;
+    for (int s = 0; s < A.S; ++s) {
+      const float a = ga[gs * s + gi];
+      sa += a;
+      sb += a * A.eps_w[(long)s * A.T.P + e];
+    }
+    dmu = A.scale_ll * sa;
+    drho = A.scale_ll * sb * sigma;
+  } else {  // radial + Trace_ELBO: pathwise through w, log p(w); d log q/d rho = -1
+    const float cs = A.c / (float)A.S;
+    for (int s = 0; s < A.S; ++s) {
+      const float er = A.eps_w[(long)s * A.T.P + e] * (A.rad_r[s * A.T.n_sites + si] / A.norms[s * A.T.n_sites + si]);
+      const float w = mu + sigma * er;
+      const float gwt = A.scale_ll * ga[gs * s + gi] + cs * (w - A.prior_loc) * inv_s0sq;
+      dmu += gwt;
+      drho += gwt * sigma * er - cs;
+    }
+  }
+  if (A.mode != 3) {  // closed-form KL(N(mu,sigma)||N(mu0,sigma0)) gradient
+    dmu += A.c * (mu - A.prior_loc) * inv_s0sq;
+    drho += A.c * (sigma * sigma * inv_s0sq - 1.f);
+  }
+  A.grad[e] = dmu;
+  A.grad[A.T.P + e] = drho;
+}
+
+// ------------------------------------------------------------------------------------------
+// ClippedAdam on the flat (mu, rho) buffer  (A12)
+// ------------------------------------------------------------------------------------------
+struct AdamArgs {
+  float* mu; float* rho; float* m; float* v; const float* grad;
+  long P;
+  float lr, beta1, beta2, eps, clip, wd, step_size, grad_scale;
+};
+
+__global__ void clipped_adam_kernel(const AdamArgs A) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * A.P) return;
+  float* p = i < A.P ? A.mu + i : A.rho + (i - A.P);
+  float g = A.grad[i] * A.grad_scale;
+  g = fminf(fmaxf(g, -A.clip), A.clip);
+  if (A.wd != 0.f) g += A.wd * *p;
+  const float m = A.beta1 * A.m[i] + (1.f - A.beta1) * g;
+  const float v = A.beta2 * A.v[i] + (1.f - A.beta2) * g * g;
+  A.m[i] = m;
+  A.v[i] = v;
+  *p -= A.step_size * m / (sqrtf(v) + A.eps);
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool1d(3,1,1) backward: dX[r][c] += sum_{r' in {r-1,r,r+1}} dP[r'][c] * [argmax(r') == r]
+// (first maximum wins on ties, as torch's max_pool backward)
+// ------------------------------------------------------------------------------------------
+__global__ void pool_bwd_kernel(const float* X, const float* dP, float* dX, long nwin, int L, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nwin * L * C) return;
+  const int c = (int)(idx % C);
+  const long rw = idx / C;
+  const int r = (int)(rw % L);
+  const long w = rw / L;
+  const float* xw = X + w * L * C + c;
+  const float* dw = dP + w * L * C + c;
+  float acc = 0.f;
+  for (int rp = max(r - 1, 0); rp <= min(r + 1, L - 1); ++rp) {
+    int am = -1;
+    float best = 0.f;
+    for (int k = max(rp - 1, 0); k <= min(rp + 1, L - 1); ++k) {
+      const float v = xw[(long)k * C];
+      if (am < 0 || v > best) {
+        best = v;
+        am = k;
+      }
+    }
+    if (am == r) acc += dw[(long)rp * C];
+  }
+  dX[idx] += acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// predictive aggregation over particles (A16), two-pass variance
+// ------------------------------------------------------------------------------------------
+__global__ void predict_finish_kernel(const float* preds /*[S][B][2]*/, int B, int S, float* out4) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float s1 = 0.f, sv = 0.f;
+  for (int s = 0; s < S; ++s) {
+    s1 += preds[((long)s * B + b) * 2];
+    const float sc = preds[((long)s * B + b) * 2 + 1];
+    sv += sc * sc;
+  }
+  const float mean = s1 / S;
+  float ss = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float d = preds[((long)s * B + b) * 2] - mean;
+    ss += d * d;
+  }
+  // unbiased variance (torch.var default); NaN at S == 1 like the reference
+  const float ep = ss / (float)(S - 1);
+  const float al = sv / S;
+  out4[b] = mean;
+  out4[B + b] = sqrtf(al + ep);
+  out4[2 * B + b] = ep;
+  out4[3 * B + b] = al;
+}

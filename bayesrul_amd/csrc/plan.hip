@@ -1,0 +1,1049 @@
+// Host side of the C ABI (include/bayesrul_amd.h): plan construction (layer / group /
+// tensor tables, workspace layout) and the launch sequences of the SVI/ELBO step.
+// gfx950 only; compiled with hipcc into libbayesrul_amd.so.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bayesrul_amd.h"
+#include "kernels_group.h"
+#include "kernels_misc.h"
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess) return fail(BNN_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+  } while (0)
+#define BNN_TRY(expr)        \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+static inline long rupl(long v, long m) { return (v + m - 1) / m * m; }
+
+// internal tensor ids (activation ids; +T_GRAD / +T_Q for twins)
+enum { TI_ACT1 = 0, TI_MID = 1, TI_ACT2 = 2, TI_H = 3, TI_Z = 4, TI_H2 = 5, TI_H3 = 6, TI_H4 = 7, TI_ACT2F = 8 };
+
+struct TensorSpec {
+  int ctot = 0;
+  int rows_per_example = 0;  // L for conv tensors, 1 for dense
+  long off = -1;             // float offset in workspace (acts); grads / q have their own
+  long goff = -1, qoff = -1;
+  int alias = -1;            // shares memory with this tensor id
+};
+
+struct BnnPlan {
+  BnnPlanDesc d;
+  int n_layers = 0, n_sites = 0, n_groups = 0;
+  long P = 0;
+  std::vector<std::string> site_names, layer_names;
+  LayerDesc layers[BNN_MAX_LAYERS];
+  ParamTable ptab;
+  GroupDesc groups[8];
+  TensorSpec tens[10];
+  long img_total = 0, imgt_total = 0;
+  int bias_total = 0;
+  long sign_in_words_total = 0, sign_out_words_total = 0;  // per example
+  long cap_windows = 0;
+  int z_t = TI_Z;
+  int x_ctot = 18;
+  // workspace layout (byte offsets)
+  size_t ws_bytes = 0;
+  size_t o_layers, o_a_hi, o_a_lo, o_b, o_at, o_bt, o_bias_a, o_bias_b, o_gw_a, o_gw_b, o_gb_a, o_gb_b, o_eps, o_radr,
+      o_norms, o_sign_in, o_sign_out, o_acc, o_scal, o_preds, o_poolgrad, o_tens;
+  size_t elem = 4;
+  bool bound = false;
+  BnnBuffers bufs{};
+  // last call geometry (for bnn_plan_tensor)
+  int last_S = 0, last_B = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// network tables
+// ------------------------------------------------------------------------------------------
+struct LSpec {
+  const char* name;
+  int is_conv, cout, cin, taps;
+  int cin_img, cmap, ca, cb;
+};
+
+static const LSpec kInception[] = {
+    {"layers.0.conv1.0", 1, 27, 18, 1, 24, CM_IDENT, 0, 0},
+    {"layers.0.conv3.0", 1, 27, 18, 3, 24, CM_IDENT, 0, 0},
+    {"layers.0.conv5.0", 1, 27, 18, 5, 24, CM_IDENT, 0, 0},
+    {"layers.0.convpool.1", 1, 27, 18, 3, 24, CM_IDENT, 0, 0},
+    {"layers.1.branch1.0", 1, 16, 108, 1, 112, CM_BLOCK, 27, 28},
+    {"layers.1.branch2.0", 1, 64, 108, 1, 112, CM_BLOCK, 27, 28},
+    {"layers.1.branch2.2", 1, 16, 64, 3, 64, CM_IDENT, 0, 0},
+    {"layers.1.branch3.0", 1, 64, 108, 1, 112, CM_BLOCK, 27, 28},
+    {"layers.1.branch3.2", 1, 16, 64, 5, 64, CM_IDENT, 0, 0},
+    {"layers.1.branch4.1", 1, 32, 108, 1, 112, CM_BLOCK, 27, 28},
+    {"layers.3", 0, 64, 2400, 1, 2400, CM_FLATTEN, 80, 30},
+    {"last", 0, 2, 64, 1, 64, CM_IDENT, 0, 0},
+};
+static const LSpec kLinear[] = {
+    {"layers.1", 0, 256, 540, 1, 544, CM_IDENT, 0, 0}, {"layers.3", 0, 128, 256, 1, 256, CM_IDENT, 0, 0},
+    {"layers.5", 0, 128, 128, 1, 128, CM_IDENT, 0, 0}, {"layers.7", 0, 32, 128, 1, 128, CM_IDENT, 0, 0},
+    {"last", 0, 2, 32, 1, 32, CM_IDENT, 0, 0},
+};
+
+static BranchDesc mk_branch(int layer, int n_off, int cout, int in_off, int cin_p, int cin_real, int pool, int relu,
+                            int out_t, int out_off, int dx_t) {
+  BranchDesc b{};
+  b.layer = layer;
+  b.n_off = n_off;
+  b.cout = cout;
+  b.ntiles = (cout + 15) / 16;
+  b.in_off = in_off;
+  b.cin_p = cin_p;
+  b.cin_real = cin_real;
+  b.pool = pool;
+  b.relu = relu;
+  b.out_t = out_t;
+  b.out_off = out_off;
+  b.q_t = out_t + T_Q;
+  b.dx_t = dx_t;
+  return b;
+}
+
+static int build_tables(BnnPlan* p) {
+  const bool inc = p->d.net == BNN_NET_INCEPTION;
+  const LSpec* ls = inc ? kInception : kLinear;
+  p->n_layers = inc ? 12 : 5;
+  const int L = p->d.win_length;
+  if (inc && (L < 1 || L > 30 + 0) && L != 30)
+    return fail(BNN_E_INVALID, "Inception needs 1 <= win_length <= 30 (one window per 32-row MFMA tile), got %d", L);
+  if (inc && L > TILE_ROWS - 2) return fail(BNN_E_INVALID, "win_length %d too long for a 32-row window tile", L);
+  if (p->d.n_features != 18) return fail(BNN_E_INVALID, "n_features must be 18 (nets/inception.py:160-162)");
+  long canon = 0, woff = 0, wtoff = 0, si_w = 0, so_w = 0;
+  int boff = 0;
+  p->ptab = ParamTable{};
+  for (int i = 0; i < p->n_layers; ++i) {
+    LayerDesc& l = p->layers[i];
+    l = LayerDesc{};
+    l.is_conv = ls[i].is_conv;
+    l.cout = ls[i].cout;
+    l.cin = ls[i].cin;
+    l.taps = ls[i].taps;
+    l.pad = (l.taps - 1) / 2;
+    l.cin_img = ls[i].cin_img;
+    l.cmap = ls[i].cmap;
+    l.cmap_a = ls[i].ca;
+    l.cmap_b = ls[i].cb;
+    if (inc && i == 10) {  // Flatten of [80, L]
+      l.cin = 80 * L;
+      l.cin_img = 80 * L;
+      l.cmap_b = L;
+      if (l.cin_img % 32) return fail(BNN_E_INVALID, "80*win_length must be a multiple of 32");
+    }
+    if (!inc && i == 0) {
+      l.cin = L * 18;
+      l.cin_img = rup(l.cin, 32);
+    }
+    l.cout_p16 = rup(l.cout, 16);
+    l.cout_p8 = rup(l.cout, 8);
+    if (!l.is_conv) l.cout_p8 = rup(l.cout, 32);  // dense dZ images are 32-wide chunks
+    l.KP = rup(l.taps * l.cin_img, 32);
+    l.KPt = rup(l.taps * l.cout_p8, 32);
+    l.cin_p16 = rup(l.cin_img, 16);
+    l.w_off = woff;
+    l.wt_off = wtoff;
+    woff += (long)l.cout_p16 * l.KP;
+    wtoff += (long)l.cin_p16 * l.KPt;
+    l.bias_off = boff;
+    boff += l.cout_p16;
+    l.canon_w = canon;
+    canon += (long)l.cout * l.cin * l.taps;
+    l.canon_b = canon;
+    canon += l.cout;
+    l.site_w = 2 * i;
+    l.site_b = 2 * i + 1;
+    l.sign_in_words = (l.cin_img + 31) / 32;
+    l.sign_out_words = (l.cout + 31) / 32;
+    l.sign_in_off = si_w;   // multiplied by examples at call time
+    l.sign_out_off = so_w;
+    si_w += l.sign_in_words;
+    so_w += l.sign_out_words;
+    p->layer_names.push_back(ls[i].name);
+    p->site_names.push_back(std::string(ls[i].name) + ".weight");
+    p->site_names.push_back(std::string(ls[i].name) + ".bias");
+    SiteDesc& sw = p->ptab.site[2 * i];
+    sw.off = l.canon_w;
+    sw.numel = (long)l.cout * l.cin * l.taps;
+    sw.layer = i;
+    sw.is_bias = 0;
+    SiteDesc& sb = p->ptab.site[2 * i + 1];
+    sb.off = l.canon_b;
+    sb.numel = l.cout;
+    sb.layer = i;
+    sb.is_bias = 1;
+  }
+  p->n_sites = 2 * p->n_layers;
+  p->P = canon;
+  p->ptab.n_sites = p->n_sites;
+  p->ptab.n_layers = p->n_layers;
+  p->ptab.P = canon;
+  p->img_total = rupl(woff, 64);
+  p->imgt_total = rupl(wtoff, 64);
+  p->bias_total = rup(boff, 16);
+  p->sign_in_words_total = si_w;
+  p->sign_out_words_total = so_w;
+
+  // tensors
+  for (auto& t : p->tens) t = TensorSpec{};
+  auto T = [&](int id, int ctot, int rpe, int alias = -1) {
+    p->tens[id].ctot = ctot;
+    p->tens[id].rows_per_example = rpe;
+    p->tens[id].alias = alias;
+  };
+  p->n_groups = 0;
+  if (inc) {
+    T(TI_ACT1, 112, L);
+    T(TI_MID, 128, L);
+    T(TI_ACT2, 80, L);
+    T(TI_ACT2F, 80 * L, 1, TI_ACT2);
+    T(TI_H, 64, 1);
+    T(TI_Z, 2, 1);
+    p->x_ctot = 18;
+    GroupDesc g{};
+    // block 1 (nets/inception.py:10-61)
+    g = GroupDesc{};
+    g.n_branch = 4; g.is_dense = 0; g.in_t = T_X; g.in_bcast = 1; g.L = L; g.in_cin_p = 24;
+    g.br[0] = mk_branch(0, 0, 27, 0, 24, 18, 0, 1, TI_ACT1, 0, -1);
+    g.br[1] = mk_branch(1, 0, 27, 0, 24, 18, 0, 1, TI_ACT1, 28, -1);
+    g.br[2] = mk_branch(2, 0, 27, 0, 24, 18, 0, 1, TI_ACT1, 56, -1);
+    g.br[3] = mk_branch(3, 0, 27, 0, 24, 18, 1, 1, TI_ACT1, 84, -1);
+    p->groups[p->n_groups++] = g;
+    // block 2, 1x1 level (nets/inception.py:71-132)
+    g = GroupDesc{};
+    g.n_branch = 4; g.is_dense = 0; g.in_t = TI_ACT1; g.in_bcast = 0; g.L = L; g.in_cin_p = 112;
+    g.br[0] = mk_branch(4, 0, 16, 0, 112, 112, 0, 1, TI_ACT2, 0, TI_ACT1 + T_GRAD);
+    g.br[1] = mk_branch(5, 0, 64, 0, 112, 112, 0, 1, TI_MID, 0, TI_ACT1 + T_GRAD);
+    g.br[2] = mk_branch(7, 0, 64, 0, 112, 112, 0, 1, TI_MID, 64, TI_ACT1 + T_GRAD);
+    g.br[3] = mk_branch(9, 0, 32, 0, 112, 112, 1, 1, TI_ACT2, 48, T_POOLGRAD);
+    p->groups[p->n_groups++] = g;
+    // block 2, k3 / k5 level
+    g = GroupDesc{};
+    g.n_branch = 2; g.is_dense = 0; g.in_t = TI_MID; g.in_bcast = 0; g.L = L; g.in_cin_p = 128;
+    g.br[0] = mk_branch(6, 0, 16, 0, 64, 64, 0, 1, TI_ACT2, 16, TI_MID + T_GRAD);
+    g.br[1] = mk_branch(8, 0, 16, 64, 64, 64, 0, 1, TI_ACT2, 32, TI_MID + T_GRAD);
+    p->groups[p->n_groups++] = g;
+    // Flatten + Linear(80*L -> 64) + ReLU
+    g = GroupDesc{};
+    g.n_branch = 1; g.is_dense = 1; g.in_t = TI_ACT2F; g.in_bcast = 0; g.L = TILE_ROWS; g.in_cin_p = 80 * L;
+    g.br[0] = mk_branch(10, 0, 64, 0, 80 * L, 80 * L, 0, 1, TI_H, 0, TI_ACT2F + T_GRAD);
+    p->groups[p->n_groups++] = g;
+    // last Linear(64 -> 2)
+    g = GroupDesc{};
+    g.n_branch = 1; g.is_dense = 1; g.in_t = TI_H; g.in_bcast = 0; g.L = TILE_ROWS; g.in_cin_p = 64;
+    g.br[0] = mk_branch(11, 0, 2, 0, 64, 64, 0, 0, TI_Z, 0, TI_H + T_GRAD);
+    p->groups[p->n_groups++] = g;
+  } else {
+    const int F = L * 18, Fp = rup(F, 32);
+    T(TI_H, 256, 1);
+    T(TI_H2, 128, 1);
+    T(TI_H3, 128, 1);
+    T(TI_H4, 32, 1);
+    T(TI_Z, 2, 1);
+    p->x_ctot = F;
+    GroupDesc g{};
+    g.n_branch = 4; g.is_dense = 1; g.in_t = T_X; g.in_bcast = 1; g.L = TILE_ROWS; g.in_cin_p = Fp;
+    for (int k = 0; k < 4; ++k) g.br[k] = mk_branch(0, 64 * k, 64, 0, Fp, F, 0, 1, TI_H, 64 * k, -1);
+    p->groups[p->n_groups++] = g;
+    g = GroupDesc{};
+    g.n_branch = 2; g.is_dense = 1; g.in_t = TI_H; g.L = TILE_ROWS; g.in_cin_p = 256;
+    for (int k = 0; k < 2; ++k) g.br[k] = mk_branch(1, 64 * k, 64, 0, 256, 256, 0, 1, TI_H2, 64 * k, TI_H + T_GRAD);
+    p->groups[p->n_groups++] = g;
+    g = GroupDesc{};
+    g.n_branch = 2; g.is_dense = 1; g.in_t = TI_H2; g.L = TILE_ROWS; g.in_cin_p = 128;
+    for (int k = 0; k < 2; ++k) g.br[k] = mk_branch(2, 64 * k, 64, 0, 128, 128, 0, 1, TI_H3, 64 * k, TI_H2 + T_GRAD);
+    p->groups[p->n_groups++] = g;
+    g = GroupDesc{};
+    g.n_branch = 1; g.is_dense = 1; g.in_t = TI_H3; g.L = TILE_ROWS; g.in_cin_p = 128;
+    g.br[0] = mk_branch(3, 0, 32, 0, 128, 128, 0, 1, TI_H4, 0, TI_H3 + T_GRAD);
+    p->groups[p->n_groups++] = g;
+    g = GroupDesc{};
+    g.n_branch = 1; g.is_dense = 1; g.in_t = TI_H4; g.L = TILE_ROWS; g.in_cin_p = 32;
+    g.br[0] = mk_branch(4, 0, 2, 0, 32, 32, 0, 0, TI_Z, 0, TI_H4 + T_GRAD);
+    p->groups[p->n_groups++] = g;
+  }
+  return 0;
+}
+
+static void layout_workspace(BnnPlan* p) {
+  const size_t el = p->d.prec == BNN_PREC_BF16X3 ? 2 : 4;
+  p->elem = el;
+  const long S = p->d.max_particles;
+  const long cap = p->cap_windows;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t r = o;
+    o += (bytes + 255) & ~(size_t)255;
+    return r;
+  };
+  p->o_layers = take(sizeof(LayerDesc) * BNN_MAX_LAYERS);
+  p->o_a_hi = take((size_t)S * p->img_total * el);
+  p->o_a_lo = take((size_t)S * p->img_total * el);
+  p->o_b = take((size_t)S * p->img_total * el);
+  p->o_at = take((size_t)S * p->imgt_total * el);
+  p->o_bt = take((size_t)S * p->imgt_total * el);
+  p->o_bias_a = take((size_t)S * p->bias_total * 4);
+  p->o_bias_b = take((size_t)p->bias_total * 4);
+  p->o_gw_a = take((size_t)S * p->img_total * 4);
+  p->o_gw_b = take((size_t)S * p->img_total * 4);
+  p->o_gb_a = take((size_t)S * p->bias_total * 4);
+  p->o_gb_b = take((size_t)S * p->bias_total * 4);
+  p->o_eps = take((size_t)S * p->P * 4);
+  p->o_radr = take((size_t)S * p->n_sites * 4);
+  p->o_norms = take((size_t)S * p->n_sites * 4);
+  p->o_sign_in = take((size_t)cap * p->sign_in_words_total * 4);
+  p->o_sign_out = take((size_t)cap * p->sign_out_words_total * 4);
+  p->o_acc = take(sizeof(double) * 2 * (S + 1));
+  p->o_scal = take(64);
+  p->o_preds = take((size_t)S * p->d.max_batch * 2 * 4);
+  p->o_poolgrad = take((size_t)cap * p->d.win_length * 112 * 4);
+  p->o_tens = o;
+  // activations / grads / q
+  long fo = 0;
+  for (int t = 0; t < 10; ++t) {
+    TensorSpec& ts = p->tens[t];
+    if (ts.ctot == 0 || ts.alias >= 0) continue;
+    const long n = rupl((long)cap * ts.rows_per_example * ts.ctot, 64);
+    ts.off = fo;
+    fo += n;
+    ts.goff = fo;
+    fo += n;
+    ts.qoff = fo;
+    fo += n;
+  }
+  for (int t = 0; t < 10; ++t) {
+    TensorSpec& ts = p->tens[t];
+    if (ts.alias >= 0) {
+      ts.off = p->tens[ts.alias].off;
+      ts.goff = p->tens[ts.alias].goff;
+      ts.qoff = p->tens[ts.alias].qoff;
+    }
+  }
+  p->ws_bytes = p->o_tens + (size_t)fo * 4;
+}
+
+// ------------------------------------------------------------------------------------------
+// API: library / plan
+// ------------------------------------------------------------------------------------------
+extern "C" int bnn_version(void) { return BNN_ABI_VERSION; }
+extern "C" const char* bnn_last_error(void) { return g_err; }
+extern "C" size_t bnn_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(BnnPlanDesc);
+    case 1: return sizeof(BnnBuffers);
+    case 2: return sizeof(BnnNoise);
+    case 3: return sizeof(BnnElboArgs);
+    case 4: return sizeof(BnnAdamArgs);
+    case 5: return sizeof(BnnElboOut);
+  }
+  return 0;
+}
+
+extern "C" int bnn_plan_create(const BnnPlanDesc* desc, BnnPlan** out) {
+  if (!desc || !out) return fail(BNN_E_INVALID, "null argument");
+  if (desc->net != BNN_NET_INCEPTION && desc->net != BNN_NET_LINEAR) return fail(BNN_E_INVALID, "unknown net %d", desc->net);
+  if (desc->mode < 0 || desc->mode > 3) return fail(BNN_E_INVALID, "unknown mode %d", desc->mode);
+  if (desc->prec != BNN_PREC_F32 && desc->prec != BNN_PREC_BF16X3) return fail(BNN_E_INVALID, "unknown prec %d", desc->prec);
+  if (desc->max_particles < 1 || desc->max_batch < 1) return fail(BNN_E_INVALID, "max_particles / max_batch must be >= 1");
+  BnnPlan* p = new BnnPlan();
+  p->d = *desc;
+  p->cap_windows = desc->max_windows > 0 ? desc->max_windows : (long)desc->max_particles * desc->max_batch;
+  if (p->cap_windows < desc->max_batch) p->cap_windows = desc->max_batch;
+  int rc = build_tables(p);
+  if (rc) {
+    delete p;
+    return rc;
+  }
+  layout_workspace(p);
+  *out = p;
+  return 0;
+}
+extern "C" void bnn_plan_destroy(BnnPlan* plan) { delete plan; }
+extern "C" int bnn_plan_num_params(const BnnPlan* p, int64_t* P) {
+  if (!p || !P) return fail(BNN_E_INVALID, "null argument");
+  *P = p->P;
+  return 0;
+}
+extern "C" int bnn_plan_num_sites(const BnnPlan* p, int32_t* n) {
+  if (!p || !n) return fail(BNN_E_INVALID, "null argument");
+  *n = p->n_sites;
+  return 0;
+}
+extern "C" int bnn_plan_num_layers(const BnnPlan* p, int32_t* n) {
+  if (!p || !n) return fail(BNN_E_INVALID, "null argument");
+  *n = p->n_layers;
+  return 0;
+}
+extern "C" int bnn_plan_workspace_bytes(const BnnPlan* p, size_t* bytes) {
+  if (!p || !bytes) return fail(BNN_E_INVALID, "null argument");
+  *bytes = p->ws_bytes;
+  return 0;
+}
+extern "C" int bnn_plan_site(const BnnPlan* p, int32_t i, const char** name, int64_t* offset, int64_t* numel) {
+  if (!p || i < 0 || i >= p->n_sites) return fail(BNN_E_INVALID, "site index out of range");
+  if (name) *name = p->site_names[i].c_str();
+  if (offset) *offset = p->ptab.site[i].off;
+  if (numel) *numel = p->ptab.site[i].numel;
+  return 0;
+}
+extern "C" int bnn_plan_layer(const BnnPlan* p, int32_t i, const char** name, int32_t* cin_img, int32_t* cout,
+                              int32_t* is_conv) {
+  if (!p || i < 0 || i >= p->n_layers) return fail(BNN_E_INVALID, "layer index out of range");
+  if (name) *name = p->layer_names[i].c_str();
+  if (cin_img) *cin_img = p->layers[i].cin_img;
+  if (cout) *cout = p->layers[i].cout;
+  if (is_conv) *is_conv = p->layers[i].is_conv;
+  return 0;
+}
+
+static float* ws_f(const BnnPlan* p, size_t off) { return (float*)((char*)p->bufs.workspace + off); }
+static float* tens_ptr(const BnnPlan* p, int t, int which /*0 act,1 grad,2 q*/) {
+  const TensorSpec& ts = p->tens[t];
+  const long o = which == 0 ? ts.off : (which == 1 ? ts.goff : ts.qoff);
+  return ws_f(p, p->o_tens) + o;
+}
+
+extern "C" int bnn_plan_bind(BnnPlan* p, const BnnBuffers* b) {
+  if (!p || !b) return fail(BNN_E_INVALID, "null argument");
+  if (!b->mu || !b->rho || !b->grad || !b->workspace) return fail(BNN_E_INVALID, "mu/rho/grad/workspace must be set");
+  if (b->workspace_bytes < p->ws_bytes)
+    return fail(BNN_E_INVALID, "workspace too small: %zu < %zu", b->workspace_bytes, p->ws_bytes);
+  if (((uintptr_t)b->workspace) & 255) return fail(BNN_E_INVALID, "workspace must be 256-byte aligned");
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(BNN_E_NO_DEVICE, "device is %s, this library is built for gfx950 only", prop.gcnArchName);
+  p->bufs = *b;
+  // zero everything once: image pads, activation pads (e.g. channel 27 of each block-1 branch)
+  HIP_TRY(hipMemset(b->workspace, 0, p->ws_bytes));
+  HIP_TRY(hipMemcpy((char*)b->workspace + p->o_layers, p->layers, sizeof(LayerDesc) * BNN_MAX_LAYERS,
+                    hipMemcpyHostToDevice));
+  p->bound = true;
+  return 0;
+}
+
+extern "C" int bnn_plan_tensor(const BnnPlan* p, int32_t which, float** ptr, int64_t* rows, int32_t* ctot) {
+  if (!p || !p->bound) return fail(BNN_E_UNBOUND, "plan not bound");
+  if (which < 0 || which > 7 || p->tens[which].ctot == 0) return fail(BNN_E_INVALID, "tensor %d not part of this net", which);
+  if (ptr) *ptr = tens_ptr(p, which, 0);
+  if (rows) *rows = (int64_t)p->last_S * p->last_B * p->tens[which].rows_per_example;
+  if (ctot) *ctot = p->tens[which].ctot;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-call context
+// ------------------------------------------------------------------------------------------
+struct Ctx {
+  int mode;  // BNN_MODE_*
+  int em;    // EM_*
+  int S, B;
+  bool radial;
+  bool train;
+  hipStream_t st;
+  const float* eps_w = nullptr;
+  const float* rad_r = nullptr;
+  float c, scale_ll, n_over_b;
+  NoiseRefs nz{};
+  int s_base = 0;  // particle offset for noise streams (predict chunks)
+};
+
+static int em_of(int mode) { return mode == BNN_MODE_LRT ? EM_LRT : (mode == BNN_MODE_FLIPOUT ? EM_FLIPOUT : EM_PLAIN); }
+
+static int make_ctx(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, void* stream, bool train, Ctx* c) {
+  if (!p || !a) return fail(BNN_E_INVALID, "null argument");
+  if (!p->bound) return fail(BNN_E_UNBOUND, "plan not bound (call bnn_plan_bind)");
+  c->mode = a->mode_override >= 0 ? a->mode_override : p->d.mode;
+  if (c->mode < 0 || c->mode > 3) return fail(BNN_E_INVALID, "bad mode %d", c->mode);
+  c->em = em_of(c->mode);
+  c->radial = c->mode == BNN_MODE_RADIAL;
+  c->S = a->particles;
+  c->B = a->batch;
+  c->train = train;
+  c->st = (hipStream_t)stream;
+  if (c->S < 1 || c->S > p->d.max_particles) return fail(BNN_E_INVALID, "particles %d outside [1, %d]", c->S, p->d.max_particles);
+  if (c->B < 1 || c->B > p->d.max_batch) return fail(BNN_E_INVALID, "batch %d outside [1, %d]", c->B, p->d.max_batch);
+  if ((long)c->S * c->B > p->cap_windows)
+    return fail(BNN_E_INVALID, "S*B = %ld exceeds the plan capacity %ld windows", (long)c->S * c->B, p->cap_windows);
+  if (a->with_obs && (!a->x || !a->y)) return fail(BNN_E_INVALID, "x / y must be set when with_obs != 0");
+  const double cc = a->scaled ? 1.0 / (a->dataset_size * p->d.win_length * p->d.n_features) : 1.0;
+  c->c = (float)cc;
+  c->n_over_b = (float)(a->dataset_size / a->batch);
+  c->scale_ll = a->with_obs ? (float)(cc * (a->dataset_size / a->batch) / c->S) : 0.f;
+  return 0;
+}
+
+template <class K>
+static int set_lds(K kernel, int bytes) {
+  HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// noise preparation: eps_w / radial r / packed signs
+// ------------------------------------------------------------------------------------------
+static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, Ctx* c) {
+  const uint64_t seed = nz ? nz->seed : 0;
+  const uint32_t step = nz ? (uint32_t)nz->step : 0;
+  c->nz.seed = seed;
+  c->nz.step = step;
+  const int S = c->S, B = c->B;
+  const bool need_eps = c->mode != BNN_MODE_LRT;
+  if (need_eps) {
+    if (nz && nz->eps_w) {
+      c->eps_w = nz->eps_w;
+    } else {
+      float* e = ws_f(p, p->o_eps);
+      const long n = ((p->P + 3) / 4) * S;
+      // particle offset is folded into the step word for predict chunks
+      gen_eps_w_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(e, p->P, S, seed + 0x9E37ull * c->s_base, step);
+      c->eps_w = e;
+    }
+  }
+  if (c->radial) {
+    if (nz && nz->radial_r) {
+      c->rad_r = nz->radial_r;
+    } else {
+      float* r = ws_f(p, p->o_radr);
+      gen_radial_r_kernel<<<dim3((S * p->n_sites + 255) / 256), dim3(256), 0, c->st>>>(r, p->n_sites, S, seed + 0x9E37ull * c->s_base, step);
+      c->rad_r = r;
+    }
+    site_norm_kernel<<<dim3(S * p->n_sites), dim3(256), 0, c->st>>>(c->eps_w, p->P, p->ptab, ws_f(p, p->o_norms));
+  }
+  // layer sign arrays live back to back: layer i at (sign_*_off * S*B) words
+  uint32_t* si = (uint32_t*)ws_f(p, p->o_sign_in);
+  uint32_t* so = (uint32_t*)ws_f(p, p->o_sign_out);
+  c->nz.sign_in = si;
+  c->nz.sign_out = so;
+  if (c->mode == BNN_MODE_FLIPOUT) {
+    const long ex = (long)S * B;
+    for (int i = 0; i < p->n_layers; ++i) {
+      const LayerDesc& l = p->layers[i];
+      uint32_t* di = si + l.sign_in_off * ex;
+      uint32_t* d_o = so + l.sign_out_off * ex;
+      if (nz && nz->sign_in && nz->sign_in[i]) {
+        const long n = ex * l.sign_in_words;
+        pack_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(nz->sign_in[i], di, ex, l.cin_img, l.sign_in_words);
+      } else {
+        const long n = ex * ((l.sign_in_words + 3) / 4);
+        gen_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(di, l.sign_in_words, S, B, a->global_batch, a->global_batch_offset, i, NK_SIGN_IN, seed, step);
+      }
+      if (nz && nz->sign_out && nz->sign_out[i]) {
+        const long n = ex * l.sign_out_words;
+        pack_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(nz->sign_out[i], d_o, ex, l.cout, l.sign_out_words);
+      } else {
+        const long n = ex * ((l.sign_out_words + 3) / 4);
+        gen_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(d_o, l.sign_out_words, S, B, a->global_batch, a->global_batch_offset, i, NK_SIGN_OUT, seed, step);
+      }
+    }
+  }
+  c->nz.use_philox_lrt = 1;
+  c->nz.examples = (long)S * B;
+  for (int i = 0; i < BNN_MAX_LAYERS; ++i) c->nz.lrt_eps[i] = nullptr;
+  if (c->mode == BNN_MODE_LRT && nz && nz->lrt_eps) {
+    c->nz.use_philox_lrt = 0;
+    for (int i = 0; i < p->n_layers; ++i) {
+      c->nz.lrt_eps[i] = nz->lrt_eps[i];
+      if (!nz->lrt_eps[i]) return fail(BNN_E_INVALID, "lrt_eps[%d] is null (inject all layers or none)", i);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// sample weights
+// ------------------------------------------------------------------------------------------
+static int do_sample(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
+  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_acc), 0, sizeof(double) * 2 * (p->d.max_particles + 1), c->st));
+  PrepArgs A{};
+  A.T = p->ptab;
+  A.layers = (const LayerDesc*)((char*)p->bufs.workspace + p->o_layers);
+  A.mu = p->bufs.mu;
+  A.rho = p->bufs.rho;
+  A.eps_w = c->eps_w;
+  A.rad_r = c->rad_r;
+  A.norms = ws_f(p, p->o_norms);
+  A.mode = c->mode;
+  A.S = c->S;
+  A.want_t = c->train ? 1 : 0;
+  char* w = (char*)p->bufs.workspace;
+  A.a_hi = w + p->o_a_hi;
+  A.a_lo = p->d.prec == BNN_PREC_BF16X3 ? w + p->o_a_lo : nullptr;
+  A.b = w + p->o_b;
+  A.at = w + p->o_at;
+  A.bt = w + p->o_bt;
+  A.slot_stride = p->img_total;
+  A.slott_stride = p->imgt_total;
+  A.bias_a = ws_f(p, p->o_bias_a);
+  A.bias_b = ws_f(p, p->o_bias_b);
+  A.bias_total = p->bias_total;
+  A.kl_acc = (double*)(w + p->o_acc);
+  A.prior_loc = (float)a->prior_loc;
+  A.prior_scale = (float)a->prior_scale;
+  const unsigned grid = (unsigned)((p->P + 255) / 256);
+  if (p->d.prec == BNN_PREC_F32)
+    prep_weights_kernel<PrecF32><<<dim3(grid), dim3(256), 0, c->st>>>(A);
+  else
+    prep_weights_kernel<PrecBF><<<dim3(grid), dim3(256), 0, c->st>>>(A);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// group launches
+// ------------------------------------------------------------------------------------------
+static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int gi, const float* x, GroupArgs* A) {
+  *A = GroupArgs{};
+  A->g = p->groups[gi];
+  A->cg.S = c->S;
+  A->cg.B = c->B;
+  A->cg.Bglob = a ? a->global_batch : c->B;
+  A->cg.goff = a ? a->global_batch_offset : 0;
+  if (A->cg.Bglob < c->B) A->cg.Bglob = c->B;
+  A->cg.per_particle = A->g.is_dense ? (c->B + TILE_ROWS - 1) / TILE_ROWS : c->B;
+  A->cg.nwin = A->cg.per_particle * c->S;
+  char* w = (char*)p->bufs.workspace;
+  const bool per_particle_a = (c->mode == BNN_MODE_NORMAL || c->mode == BNN_MODE_RADIAL);
+  const bool per_particle_b = (c->mode == BNN_MODE_FLIPOUT);
+  A->ws.a_hi = w + p->o_a_hi;
+  A->ws.a_lo = w + p->o_a_lo;
+  A->ws.b = w + p->o_b;
+  A->ws.at = w + p->o_at;
+  A->ws.bt = w + p->o_bt;
+  A->ws.bias_a = ws_f(p, p->o_bias_a);
+  A->ws.bias_b = ws_f(p, p->o_bias_b);
+  A->ws.slot_stride_a = per_particle_a ? p->img_total : 0;
+  A->ws.slot_stride_b = per_particle_b ? p->img_total : 0;
+  A->ws.slott_stride_a = per_particle_a ? p->imgt_total : 0;
+  A->ws.slott_stride_b = per_particle_b ? p->imgt_total : 0;
+  A->ws.bias_stride_a = (c->mode == BNN_MODE_LRT) ? 0 : p->bias_total;
+  A->ws.bias_total = p->bias_total;
+  A->nz = c->nz;
+  for (int t = 0; t < 10; ++t) {
+    if (p->tens[t].ctot == 0) continue;
+    A->t[t] = TensorRef{tens_ptr(p, t, 0), p->tens[t].ctot, 0};
+    A->t[t + T_GRAD] = TensorRef{tens_ptr(p, t, 1), p->tens[t].ctot, 0};
+    A->t[t + T_Q] = TensorRef{tens_ptr(p, t, 2), p->tens[t].ctot, 0};
+  }
+  A->t[T_X] = TensorRef{const_cast<float*>(x), p->x_ctot, 0};
+  A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), 112, 0};
+  A->layers = (const LayerDesc*)(w + p->o_layers);
+  A->gw_a = ws_f(p, p->o_gw_a);
+  A->gw_b = ws_f(p, p->o_gw_b);
+  A->gb_a = ws_f(p, p->o_gb_a);
+  A->gb_b = ws_f(p, p->o_gb_b);
+  A->gw_stride = p->img_total;
+  A->gb_stride = p->bias_total;
+}
+
+static int img_bytes(int ch, bool bf) { return (IMG_ROWS * img_row_stride(ch, bf) * (bf ? 2 : 4) + 15) & ~15; }
+
+template <class P>
+static int launch_fwd(const GroupArgs& A0, int em, hipStream_t st) {
+  GroupArgs A = A0;
+  const int nimg = P::BF ? 3 : 2;
+  A.lds_per_wave = nimg * img_bytes(DENSE_CHUNK, P::BF);
+  const int lds = 4 * A.lds_per_wave;
+  const unsigned grid = (unsigned)std::min((A.cg.nwin + 3) / 4, 2048);
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(group_fwd_kernel<P, EM_PLAIN>, lds));
+    group_fwd_kernel<P, EM_PLAIN><<<dim3(grid), dim3(256), lds, st>>>(A);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(group_fwd_kernel<P, EM_LRT>, lds));
+    group_fwd_kernel<P, EM_LRT><<<dim3(grid), dim3(256), lds, st>>>(A);
+  } else {
+    BNN_TRY(set_lds(group_fwd_kernel<P, EM_FLIPOUT>, lds));
+    group_fwd_kernel<P, EM_FLIPOUT><<<dim3(grid), dim3(256), lds, st>>>(A);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <class P>
+static int launch_dx(const GroupArgs& A0, int em, int pool_sel, hipStream_t st) {
+  GroupArgs A = A0;
+  A.pool_sel = pool_sel;
+  A.lds_per_wave = 2 * img_bytes(DENSE_CHUNK, P::BF);
+  const int lds = 4 * A.lds_per_wave;
+  const unsigned grid = (unsigned)std::min((A.cg.nwin + 3) / 4, 2048);
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(group_dx_kernel<P, EM_PLAIN>, lds));
+    group_dx_kernel<P, EM_PLAIN><<<dim3(grid), dim3(256), lds, st>>>(A);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(group_dx_kernel<P, EM_LRT>, lds));
+    group_dx_kernel<P, EM_LRT><<<dim3(grid), dim3(256), lds, st>>>(A);
+  } else {
+    BNN_TRY(set_lds(group_dx_kernel<P, EM_FLIPOUT>, lds));
+    group_dx_kernel<P, EM_FLIPOUT><<<dim3(grid), dim3(256), lds, st>>>(A);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <class P, int NW>
+static int launch_dw(const GroupArgs& A0, int em, hipStream_t st) {
+  GroupArgs A = A0;
+  A.lds_per_wave = 2 * img_bytes(64, P::BF) + 2 * img_bytes(DENSE_CHUNK, P::BF);
+  const int lds = NW * A.lds_per_wave;
+  int njobs = 0;
+  for (int b = 0; b < A.g.n_branch; ++b) njobs += (A.g.br[b].cin_p + DENSE_CHUNK - 1) / DENSE_CHUNK;
+  const int max_split = std::max(1, (A.cg.per_particle + NW - 1) / NW);
+  int nsplit = std::max(1, 768 / std::max(1, njobs * A.cg.S));
+  nsplit = std::min(nsplit, max_split);
+  A.nsplit = nsplit;
+  const unsigned grid = (unsigned)(njobs * A.cg.S * nsplit);
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(group_dw_kernel<P, EM_PLAIN, NW>, lds));
+    group_dw_kernel<P, EM_PLAIN, NW><<<dim3(grid), dim3(NW * 64), lds, st>>>(A);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(group_dw_kernel<P, EM_LRT, NW>, lds));
+    group_dw_kernel<P, EM_LRT, NW><<<dim3(grid), dim3(NW * 64), lds, st>>>(A);
+  } else {
+    BNN_TRY(set_lds(group_dw_kernel<P, EM_FLIPOUT, NW>, lds));
+    group_dw_kernel<P, EM_FLIPOUT, NW><<<dim3(grid), dim3(NW * 64), lds, st>>>(A);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
+  for (int gi = 0; gi < p->n_groups; ++gi) {
+    GroupArgs A;
+    fill_group_args(p, a, c, gi, x, &A);
+    if (p->d.prec == BNN_PREC_F32)
+      BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st));
+    else
+      BNN_TRY(launch_fwd<PrecBF>(A, c->em, c->st));
+  }
+  p->last_S = c->S;
+  p->last_B = c->B;
+  return 0;
+}
+
+static int do_head(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, float* preds, bool want_dz) {
+  HeadArgs H{};
+  H.z = tens_ptr(p, p->z_t, 0);
+  H.y = a->y;
+  H.dz = want_dz ? tens_ptr(p, p->z_t, 1) : nullptr;
+  H.preds = preds;
+  H.ll_acc = (double*)((char*)p->bufs.workspace + p->o_acc) + (p->d.max_particles + 1);
+  H.S = c->S;
+  H.B = c->B;
+  H.with_obs = a->with_obs && a->y;
+  head_nll_kernel<<<dim3((c->B + 255) / 256, c->S), dim3(256), 0, c->st>>>(H);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
+  const size_t gwb = (size_t)c->S * p->img_total * 4, gbb = (size_t)c->S * p->bias_total * 4;
+  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gw_a), 0, gwb, c->st));
+  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gw_b), 0, gwb, c->st));
+  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gb_a), 0, gbb, c->st));
+  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gb_b), 0, gbb, c->st));
+  for (int gi = p->n_groups - 1; gi >= 0; --gi) {
+    GroupArgs A;
+    fill_group_args(p, a, c, gi, a->x, &A);
+    if (p->d.prec == BNN_PREC_F32)
+      BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st)));
+    else
+      BNN_TRY((launch_dw<PrecBF, 4>(A, c->em, c->st)));
+    bool any_direct = false, any_pool = false;
+    for (int b = 0; b < A.g.n_branch; ++b) {
+      if (A.g.br[b].dx_t < 0) continue;
+      (A.g.br[b].pool ? any_pool : any_direct) = true;
+    }
+    if (any_direct) {
+      if (p->d.prec == BNN_PREC_F32)
+        BNN_TRY(launch_dx<PrecF32>(A, c->em, 0, c->st));
+      else
+        BNN_TRY(launch_dx<PrecBF>(A, c->em, 0, c->st));
+    }
+    if (any_pool) {
+      if (p->d.prec == BNN_PREC_F32)
+        BNN_TRY(launch_dx<PrecF32>(A, c->em, 1, c->st));
+      else
+        BNN_TRY(launch_dx<PrecBF>(A, c->em, 1, c->st));
+      // scatter through the arg-max of MaxPool1d(3,1,1) into the direct gradient
+      const int tin = A.g.in_t;
+      const long nwin = (long)c->S * c->B;
+      const int C = p->tens[tin].ctot, L = A.g.L;
+      const long n = nwin * L * C;
+      pool_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(
+          tens_ptr(p, tin, 0), ws_f(p, p->o_poolgrad), tens_ptr(p, tin, 1), nwin, L, C);
+      HIP_TRY(hipGetLastError());
+    }
+  }
+  return 0;
+}
+
+static int do_finalize(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
+  FinalizeArgs F{};
+  F.T = p->ptab;
+  F.layers = (const LayerDesc*)((char*)p->bufs.workspace + p->o_layers);
+  F.mu = p->bufs.mu;
+  F.rho = p->bufs.rho;
+  F.eps_w = c->eps_w;
+  F.rad_r = c->rad_r;
+  F.norms = ws_f(p, p->o_norms);
+  F.gw_a = ws_f(p, p->o_gw_a);
+  F.gw_b = ws_f(p, p->o_gw_b);
+  F.gb_a = ws_f(p, p->o_gb_a);
+  F.gb_b = ws_f(p, p->o_gb_b);
+  F.gw_stride = p->img_total;
+  F.gb_stride = p->bias_total;
+  F.mode = c->mode;
+  F.S = c->S;
+  F.scale_ll = c->scale_ll;
+  F.c = c->c;
+  F.prior_loc = (float)a->prior_loc;
+  F.prior_scale = (float)a->prior_scale;
+  F.grad = p->bufs.grad;
+  grad_finalize_kernel<<<dim3((unsigned)((p->P + 255) / 256)), dim3(256), 0, c->st>>>(F);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int do_loss(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElboOut* out, bool to_grad) {
+  LossArgs LA{};
+  double* acc = (double*)((char*)p->bufs.workspace + p->o_acc);
+  LA.kl_acc = acc;
+  LA.ll_acc = acc + (p->d.max_particles + 1);
+  LA.S = c->S;
+  LA.radial = c->radial;
+  LA.c = c->c;
+  LA.n_over_b = a->with_obs ? c->n_over_b : 0.0;
+  float* scal = ws_f(p, p->o_scal);
+  LA.loss = (out && out->loss) ? out->loss : scal;
+  LA.kl = (out && out->kl) ? out->kl : scal + 1;
+  LA.ll = (out && out->loglik) ? out->loglik : scal + 2;
+  LA.grad_tail = to_grad ? p->bufs.grad + 2 * p->P : nullptr;
+  finish_loss_kernel<<<dim3(1), dim3(64), 0, c->st>>>(LA);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int do_adam(BnnPlan* p, const BnnAdamArgs* ad, hipStream_t st) {
+  if (!p->bufs.adam_m || !p->bufs.adam_v) return fail(BNN_E_INVALID, "adam_m / adam_v not bound");
+  AdamArgs A{};
+  A.mu = p->bufs.mu;
+  A.rho = p->bufs.rho;
+  A.m = p->bufs.adam_m;
+  A.v = p->bufs.adam_v;
+  A.grad = p->bufs.grad;
+  A.P = p->P;
+  A.lr = (float)ad->lr;
+  A.beta1 = (float)ad->beta1;
+  A.beta2 = (float)ad->beta2;
+  A.eps = (float)ad->eps;
+  A.clip = (float)ad->clip_norm;
+  A.wd = (float)ad->weight_decay;
+  const double bc1 = 1.0 - std::pow(ad->beta1, (double)ad->step);
+  const double bc2 = 1.0 - std::pow(ad->beta2, (double)ad->step);
+  A.step_size = (float)(ad->lr * std::sqrt(bc2) / bc1);
+  A.grad_scale = (float)(ad->grad_scale == 0.0 ? 1.0 : ad->grad_scale);
+  clipped_adam_kernel<<<dim3((unsigned)((2 * p->P + 255) / 256)), dim3(256), 0, st>>>(A);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// API: ops and steps
+// ------------------------------------------------------------------------------------------
+extern "C" int bnn_sample_weights(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, void* stream) {
+  Ctx c;
+  BNN_TRY(make_ctx(p, a, nz, stream, true, &c));
+  BNN_TRY(prepare_noise(p, a, nz, &c));
+  return do_sample(p, a, &c);
+}
+
+extern "C" int bnn_forward(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, void* stream) {
+  Ctx c;
+  BNN_TRY(make_ctx(p, a, nz, stream, true, &c));
+  if (!a->x) return fail(BNN_E_INVALID, "x is null");
+  BNN_TRY(prepare_noise(p, a, nz, &c));
+  return do_forward(p, a, &c, a->x);
+}
+
+extern "C" int bnn_head_nll(BnnPlan* p, const BnnElboArgs* a, const BnnElboOut* out, void* stream) {
+  Ctx c;
+  BNN_TRY(make_ctx(p, a, nullptr, stream, true, &c));
+  HIP_TRY(hipMemsetAsync((double*)((char*)p->bufs.workspace + p->o_acc) + (p->d.max_particles + 1), 0,
+                         sizeof(double) * (p->d.max_particles + 1), c.st));
+  BNN_TRY(do_head(p, a, &c, out ? out->preds : nullptr, true));
+  return do_loss(p, a, &c, out, false);
+}
+
+extern "C" int bnn_backward(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, void* stream) {
+  Ctx c;
+  BNN_TRY(make_ctx(p, a, nz, stream, true, &c));
+  BNN_TRY(prepare_noise(p, a, nz, &c));
+  return do_backward(p, a, &c);
+}
+
+extern "C" int bnn_grad_finalize(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, void* stream) {
+  Ctx c;
+  BNN_TRY(make_ctx(p, a, nz, stream, true, &c));
+  BNN_TRY(prepare_noise(p, a, nz, &c));
+  return do_finalize(p, a, &c);
+}
+
+extern "C" int bnn_clipped_adam(BnnPlan* p, const BnnAdamArgs* ad, void* stream) {
+  if (!p || !ad) return fail(BNN_E_INVALID, "null argument");
+  if (!p->bound) return fail(BNN_E_UNBOUND, "plan not bound");
+  return do_adam(p, ad, (hipStream_t)stream);
+}
+
+extern "C" int bnn_elbo_step(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, const BnnAdamArgs* adam,
+                             const BnnElboOut* out, void* stream) {
+  Ctx c;
+  BNN_TRY(make_ctx(p, a, nz, stream, true, &c));
+  if (!a->with_obs) return fail(BNN_E_INVALID, "bnn_elbo_step needs with_obs = 1");
+  BNN_TRY(prepare_noise(p, a, nz, &c));
+  BNN_TRY(do_sample(p, a, &c));
+  BNN_TRY(do_forward(p, a, &c, a->x));
+  BNN_TRY(do_head(p, a, &c, out ? out->preds : nullptr, true));
+  BNN_TRY(do_backward(p, a, &c));
+  BNN_TRY(do_finalize(p, a, &c));
+  BNN_TRY(do_loss(p, a, &c, out, true));
+  if (adam) BNN_TRY(do_adam(p, adam, c.st));
+  return 0;
+}
+
+extern "C" int bnn_elbo_evaluate(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, const BnnElboOut* out,
+                                 void* stream) {
+  Ctx c;
+  BNN_TRY(make_ctx(p, a, nz, stream, false, &c));
+  BNN_TRY(prepare_noise(p, a, nz, &c));
+  BNN_TRY(do_sample(p, a, &c));
+  if (a->with_obs) {
+    BNN_TRY(do_forward(p, a, &c, a->x));
+    BNN_TRY(do_head(p, a, &c, out ? out->preds : nullptr, false));
+  }
+  return do_loss(p, a, &c, out, false);
+}
+
+extern "C" int bnn_predict(BnnPlan* p, const float* x, int32_t batch, int32_t particles, const BnnNoise* nz,
+                           float* preds_sb2, float* out4, void* stream) {
+  if (!p || !x) return fail(BNN_E_INVALID, "null argument");
+  if (!p->bound) return fail(BNN_E_UNBOUND, "plan not bound");
+  if (batch < 1 || batch > p->d.max_batch) return fail(BNN_E_INVALID, "batch %d outside [1, %d]", batch, p->d.max_batch);
+  if (particles < 1) return fail(BNN_E_INVALID, "particles must be >= 1");
+  int chunk = (int)std::min<long>(p->d.max_particles, p->cap_windows / batch);
+  if (chunk < 1) return fail(BNN_E_INVALID, "plan capacity (%ld windows) below one particle of batch %d", p->cap_windows, batch);
+  float* preds_all = preds_sb2;
+  if (!preds_all) {
+    if (particles > p->d.max_particles)
+      return fail(BNN_E_INVALID, "without a preds buffer particles must be <= max_particles (%d)", p->d.max_particles);
+    preds_all = ws_f(p, p->o_preds);
+  }
+  if (nz && (nz->lrt_eps || nz->sign_in || nz->sign_out))
+    return fail(BNN_E_INVALID, "bnn_predict samples weights plainly (bayesian.py:231-250): only eps_w / radial_r may be injected");
+  for (int s0 = 0; s0 < particles; s0 += chunk) {
+    const int sc = std::min(chunk, particles - s0);
+    BnnElboArgs a{};
+    a.x = x;
+    a.y = nullptr;
+    a.batch = batch;
+    a.particles = sc;
+    a.global_batch = batch;
+    a.global_batch_offset = 0;
+    a.dataset_size = 1.0;
+    a.prior_loc = 0.0;
+    a.prior_scale = 1.0;
+    a.mode_override = p->d.mode == BNN_MODE_RADIAL ? BNN_MODE_RADIAL : BNN_MODE_NORMAL;
+    a.with_obs = 0;
+    a.scaled = 0;
+    BnnNoise n2{};
+    if (nz) n2 = *nz;
+    if (n2.eps_w) n2.eps_w += (long)s0 * p->P;
+    if (n2.radial_r) n2.radial_r += (long)s0 * p->n_sites;
+    Ctx c;
+    BNN_TRY(make_ctx(p, &a, &n2, stream, false, &c));
+    c.s_base = s0;
+      BNN_TRY(prepare_noise(p, &a, &n2, &c));
+    BNN_TRY(do_sample(p, &a, &c));
+    BNN_TRY(do_forward(p, &a, &c, x));
+    BNN_TRY(do_head(p, &a, &c, preds_all + (long)s0 * batch * 2, false));
+  }
+  if (out4) {
+    predict_finish_kernel<<<dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(preds_all, batch, particles, out4);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" int bnn_export_noise(BnnPlan* p, const BnnElboArgs* a, uint64_t seed, uint64_t step, float* eps_w,
+                                float* radial_r, float* const* lrt_eps, float* const* sign_in, float* const* sign_out,
+                                void* stream) {
+  Ctx c;
+  BnnNoise nz{};
+  nz.seed = seed;
+  nz.step = step;
+  BNN_TRY(make_ctx(p, a, &nz, stream, false, &c));
+  const int S = c.S, B = c.B;
+  const uint32_t st32 = (uint32_t)step;
+  if (eps_w) {
+    const long n = ((p->P + 3) / 4) * S;
+    gen_eps_w_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st>>>(eps_w, p->P, S, seed, st32);
+  }
+  if (radial_r)
+    gen_radial_r_kernel<<<dim3((S * p->n_sites + 255) / 256), dim3(256), 0, c.st>>>(radial_r, p->n_sites, S, seed, st32);
+  CallGeom cg{};
+  cg.S = S;
+  cg.B = B;
+  cg.Bglob = std::max(a->global_batch, B);
+  cg.goff = a->global_batch_offset;
+  const long ex = (long)S * B;
+  uint32_t* tmp = (uint32_t*)ws_f(p, p->o_sign_in);
+  for (int i = 0; i < p->n_layers; ++i) {
+    const LayerDesc& l = p->layers[i];
+    const int Lrows = l.is_conv ? p->d.win_length : 1;
+    if (lrt_eps && lrt_eps[i]) {
+      const long rows = ex * Lrows;
+      const long n = rows * ((l.cout + 3) / 4);
+      export_lrt_eps_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st>>>(lrt_eps[i], rows, l.cout, l.cout_p16, Lrows, cg, i, seed, st32);
+    }
+    if (sign_in && sign_in[i]) {
+      const long n = ex * ((l.sign_in_words + 3) / 4);
+      gen_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st>>>(tmp, l.sign_in_words, S, B, cg.Bglob, cg.goff, i, NK_SIGN_IN, seed, st32);
+      const long m = ex * l.cin_img;
+      unpack_signs_kernel<<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c.st>>>(tmp, sign_in[i], ex, l.cin_img, l.sign_in_words);
+    }
+    if (sign_out && sign_out[i]) {
+      const long n = ex * ((l.sign_out_words + 3) / 4);
+      gen_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.st>>>(tmp, l.sign_out_words, S, B, cg.Bglob, cg.goff, i, NK_SIGN_OUT, seed, st32);
+      const long m = ex * l.cout;
+      unpack_signs_kernel<<<dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c.st>>>(tmp, sign_out[i], ex, l.cout, l.sign_out_words);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

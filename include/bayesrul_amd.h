@@ -1,0 +1,185 @@
+/*
+ * bayesrul_amd.h — C ABI of the MI355X-native SVI/ELBO hot path of lbasora/bayesrul.
+ *
+ * The reference has NO native interface for this path: the boundary is the
+ * Python class `bayesrul.models.bayesian.BNN` which delegates the arithmetic to Pyro/TyXe.
+ * Each entry point below cites the reference call site(s) whose arithmetic it replaces.
+ * The Python host (`bayesrul_amd/`) binds these with ctypes; no torch
+ * types cross this boundary: plain device pointers, sizes and a hipStream_t (as void*).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative BNN_E_* code on failure; the message is
+ *     available from bnn_last_error() (thread-local).  No C++ exception crosses the ABI.
+ *   - all device memory is owned by the caller (PyTorch's caching allocator in the Python
+ *     host); the library allocates nothing on the device.  Functions only enqueue work on the
+ *     given stream and never synchronise.
+ *   - parameters live in ONE flat fp32 buffer in the reference's own layout
+ *     (`named_parameters` order, PyTorch [Cout,Cin,k] / [out,in] element order):
+ *     mu[P], rho[P] (= log sigma, unconstrained), Adam m[2P], v[2P], grad[2P+2].
+ */
+#ifndef BAYESRUL_AMD_H
+#define BAYESRUL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNN_ABI_VERSION 1
+
+enum {
+  BNN_OK = 0,
+  BNN_E_INVALID = -1,   /* bad argument / unsupported configuration */
+  BNN_E_UNBOUND = -2,   /* plan used before bnn_plan_bind */
+  BNN_E_HIP = -3,       /* a HIP runtime call failed */
+  BNN_E_NO_DEVICE = -4  /* no gfx950 device / kernel image not loadable */
+};
+
+/* network: bayesrul/models/nets/inception.py:142-217, nets/linear.py:10-72 (out_size=2) */
+enum { BNN_NET_INCEPTION = 0, BNN_NET_LINEAR = 1 };
+/* estimator: bayesian.py:66-85 (fit_context lrt|flipout|null, guide normal|radial) */
+enum { BNN_MODE_NORMAL = 0, BNN_MODE_LRT = 1, BNN_MODE_FLIPOUT = 2, BNN_MODE_RADIAL = 3 };
+/* contraction arithmetic: exact f32 MFMA, or split-bf16 (hi+lo, 3 MFMAs on the mean path)
+ * with fp32 accumulation */
+enum { BNN_PREC_F32 = 0, BNN_PREC_BF16X3 = 1 };
+
+typedef struct BnnPlan BnnPlan;
+
+typedef struct BnnPlanDesc {
+  int32_t net;            /* BNN_NET_* */
+  int32_t mode;           /* BNN_MODE_* used by bnn_elbo_* (training estimator) */
+  int32_t prec;           /* BNN_PREC_* */
+  int32_t max_particles;  /* S_max: largest mc_samples_{train,eval} the plan must hold */
+  int32_t max_batch;      /* B_max: largest per-call batch (windows) */
+  int32_t win_length;     /* W (30) */
+  int32_t n_features;     /* F (18) */
+  int32_t max_windows;    /* capacity S*B of one launch (0: max_particles*max_batch); bnn_predict
+                             walks the particles in chunks of max_windows / batch */
+} BnnPlanDesc;
+
+/* device buffers the plan works on; all caller-owned */
+typedef struct BnnBuffers {
+  float* mu;       /* [P]  variational means, reference layout */
+  float* rho;      /* [P]  log sigma */
+  float* adam_m;   /* [2P] */
+  float* adam_v;   /* [2P] */
+  float* grad;     /* [2P+2]: d loss/d mu, d loss/d rho, loss, kl  (the DP all-reduce payload) */
+  void*  workspace;
+  size_t workspace_bytes;
+} BnnBuffers;
+
+/* per-call noise: either Philox (all pointers NULL) or injected (parity tests) */
+typedef struct BnnNoise {
+  uint64_t seed;           /* Philox key */
+  uint64_t step;           /* Philox stream offset (the optimiser step) */
+  const float* eps_w;      /* [S][P] weight noise, reference layout, or NULL */
+  const float* radial_r;   /* [S][n_sites] radial distances, or NULL */
+  const float* const* lrt_eps;   /* [n_layers] -> [S][B][L][Cout] (channels-last) or NULL */
+  const float* const* sign_in;   /* [n_layers] -> [S][B][Cin_img] of +-1, or NULL */
+  const float* const* sign_out;  /* [n_layers] -> [S][B][Cout]    of +-1, or NULL */
+} BnnNoise;
+
+typedef struct BnnElboArgs {
+  const float* x;          /* [B][W][F] fp32 windows (NCMAPSSLmdbDataset layout, dataset.py:13-16) */
+  const float* y;          /* [B] labels */
+  int32_t batch;           /* B (local) */
+  int32_t particles;       /* S = mc_samples_train */
+  int32_t global_batch_offset; /* index of this rank's first window in the global batch (DP noise) */
+  int32_t global_batch;    /* B_global (== batch on one GPU) */
+  double dataset_size;     /* N */
+  double prior_loc, prior_scale;
+  int32_t mode_override;   /* -1: plan mode; else BNN_MODE_* (validation = plain sampling) */
+  int32_t with_obs;        /* 0: svi_no_obs (KL only), 1: full ELBO */
+  int32_t scaled;          /* 1: poutine.scale 1/(N*W*F) applied (bayesian.py:111-129) */
+  int32_t reserved;
+} BnnElboArgs;
+
+typedef struct BnnAdamArgs {
+  double lr, beta1, beta2, eps, clip_norm, weight_decay;
+  int64_t step;            /* 1-based step count after increment */
+  double grad_scale;       /* multiplies grad before the clamp (1/world_size after a sum all-reduce) */
+} BnnAdamArgs;
+
+/* scalars + predictions produced by a step; device pointers into caller memory */
+typedef struct BnnElboOut {
+  float* loss;     /* [1]  the value svi.step returns */
+  float* kl;       /* [1]  unscaled KL (or log q - log p), particle mean */
+  float* loglik;   /* [1]  sum_b log N(y_b; ...), particle mean */
+  float* preds;    /* [S][B][2] net outputs (loc, scale after softplus+threshold) or NULL */
+} BnnElboOut;
+
+/* ---- library ---- */
+int bnn_version(void);
+const char* bnn_last_error(void);
+/* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
+ * 0 BnnPlanDesc, 1 BnnBuffers, 2 BnnNoise, 3 BnnElboArgs, 4 BnnAdamArgs, 5 BnnElboOut */
+size_t bnn_abi_sizeof(int which);
+
+/* ---- plan: replaces BNN.define_bnn / on_fit_start bookkeeping (bayesian.py:45-132) ---- */
+int bnn_plan_create(const BnnPlanDesc* desc, BnnPlan** out);
+void bnn_plan_destroy(BnnPlan* plan);
+int bnn_plan_num_params(const BnnPlan* plan, int64_t* P);
+int bnn_plan_num_sites(const BnnPlan* plan, int32_t* n_sites);
+int bnn_plan_num_layers(const BnnPlan* plan, int32_t* n_layers);
+int bnn_plan_workspace_bytes(const BnnPlan* plan, size_t* bytes);
+int bnn_plan_bind(BnnPlan* plan, const BnnBuffers* bufs);
+/* site table: name / offset / numel of site i in the flat buffers */
+int bnn_plan_site(const BnnPlan* plan, int32_t i, const char** name, int64_t* offset, int64_t* numel);
+/* layer table: image-channel count an injected sign_in row must have, and Cout */
+int bnn_plan_layer(const BnnPlan* plan, int32_t i, const char** name, int32_t* cin_img, int32_t* cout,
+                   int32_t* is_conv);
+/* debug/test access to intermediate activations of the last forward: tensor `which`
+ * (see BNN_T_*), returns device pointer + row count + channel count */
+enum { BNN_T_ACT1 = 0, BNN_T_MID = 1, BNN_T_ACT2 = 2, BNN_T_H = 3, BNN_T_Z = 4,
+       BNN_T_H2 = 5, BNN_T_H3 = 6, BNN_T_H4 = 7 };
+int bnn_plan_tensor(const BnnPlan* plan, int32_t which, float** ptr, int64_t* rows, int32_t* ctot);
+
+/* ---- kernels, one entry per family ---- */
+
+/* A7/A8/A10: AutoNormal / RadialNormal.rsample (guides/radial.py:31-41) / flipout dW: builds
+ * the per-particle weight images the contraction kernels consume and the KL (A5) or
+ * log q - log p (A6) reductions. */
+int bnn_sample_weights(BnnPlan* plan, const BnnElboArgs* a, const BnnNoise* noise, void* stream);
+
+/* A9/A10/A13/A14: S x B variational forwards of the net (LRT / Flipout / plain sampled) */
+int bnn_forward(BnnPlan* plan, const BnnElboArgs* a, const BnnNoise* noise, void* stream);
+
+/* A11: softplus -> Threshold -> (likelihood softplus) -> Gaussian log-lik, and its backward */
+int bnn_head_nll(BnnPlan* plan, const BnnElboArgs* a, const BnnElboOut* out, void* stream);
+
+/* backward of bnn_forward: activation grads + weight-image grads */
+int bnn_backward(BnnPlan* plan, const BnnElboArgs* a, const BnnNoise* noise, void* stream);
+
+/* chain rule to (mu, rho) + KL / prior terms -> grad[2P+2] (A5/A6) */
+int bnn_grad_finalize(BnnPlan* plan, const BnnElboArgs* a, const BnnNoise* noise, void* stream);
+
+/* A12: pyro.optim.ClippedAdam on the flat (mu, rho) buffer (conf/model/bnn.yaml:6-10) */
+int bnn_clipped_adam(BnnPlan* plan, const BnnAdamArgs* a, void* stream);
+
+/* A4: svi.step = sample -> forward -> head -> backward -> finalize [-> adam if adam != NULL].
+ * With adam == NULL the caller all-reduces grad[2P+2] (RCCL) and calls bnn_clipped_adam. */
+int bnn_elbo_step(BnnPlan* plan, const BnnElboArgs* a, const BnnNoise* noise, const BnnAdamArgs* adam,
+                  const BnnElboOut* out, void* stream);
+
+/* A4: svi.evaluate_loss (no grad): sample -> forward -> head */
+int bnn_elbo_evaluate(BnnPlan* plan, const BnnElboArgs* a, const BnnNoise* noise, const BnnElboOut* out,
+                      void* stream);
+
+/* A16: bnn.predict(x, num_predictions=S, aggregate=False) + the aggregation of
+ * predict_step / test_step (bayesian.py:203-250): out4 = [4][B] (preds, stds, ep_vars, al_vars);
+ * preds_sb2 (optional) = [S][B][2] raw net outputs. */
+int bnn_predict(BnnPlan* plan, const float* x, int32_t batch, int32_t particles, const BnnNoise* noise,
+                float* preds_sb2, float* out4, void* stream);
+
+/* test helper: writes the Philox noise the kernels would draw for (seed, step) into caller
+ * buffers with the layouts of BnnNoise, so an oracle can replay identical noise. */
+int bnn_export_noise(BnnPlan* plan, const BnnElboArgs* a, uint64_t seed, uint64_t step, float* eps_w,
+                     float* radial_r, float* const* lrt_eps, float* const* sign_in, float* const* sign_out,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYESRUL_AMD_H */

@@ -1,0 +1,213 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on identical injected noise.
+
+f32 plans use the exact-fp32 MFMA (tight tolerances); bf16x3 plans use split-bf16 on the
+forward mean path (ELBO tolerance 1e-3 relative is the north star's; we hold 1e-4) and single
+bf16 in the backward contractions (gradient tolerance is a relative L2 error).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import restatement as R
+from tests.noise_util import flat, from_injected, oracle_cfg, rel_l2, synth_batch, to_injected
+
+HYP = {"lrt": (0.138793, 0.001351, 8.57e-4), "flipout": (0.198768, 0.000214, 9.48e-4),
+       "radial": (0.092516, 0.001241, 9.56e-4), "normal": (0.15, 0.002, 9e-4)}
+N_DATA = 238200
+
+
+def _engine(net, mode, prec, S, B, **kw):
+    from bayesrul_amd.engine import SviEngine
+    guide = "radial" if mode == "radial" else "normal"
+    ctx = mode if mode in ("lrt", "flipout") else None
+    return SviEngine(net=net, guide=guide, fit_context=ctx, prec=prec, max_particles=S, max_batch=B, **kw)
+
+
+def _setup(net, mode, prec, S, B, q_boost=1.0, seed=0):
+    ps, qs, lr = HYP[mode]
+    qs *= q_boost
+    eng = _engine(net, mode, prec, S, B)
+    mu0 = R.init_mu0(net, seed, torch.float64)
+    eng.init_params(mu0, qs)
+    cfg = oracle_cfg(net, mode, ps)
+    st = R.SviState(cfg, mu0, qs, R.AdamConfig(lr=lr))
+    x, y = synth_batch(B)
+    noise = R.make_noise(cfg, B, S, torch.Generator().manual_seed(4321))
+    return eng, cfg, st, x, y, noise, (ps, qs, lr)
+
+
+@pytest.mark.parametrize("mode", ["lrt", "flipout", "radial", "normal"])
+@pytest.mark.parametrize("net", ["inception", "linear"])
+def test_step_f32_matches_oracle(net, mode):
+    """loss / kl / loglik / preds / d(mu, rho) of one svi.step, exact-fp32 MFMA path.
+    q_scale x20 so that every variance / perturbation term is far above fp32 round-off."""
+    S, B = 2, 7
+    eng, cfg, st, x, y, noise, (ps, qs, lr) = _setup(net, mode, "f32", S, B, q_boost=20.0)
+    inj = to_injected(eng, cfg, noise, B)
+    res, preds = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, noise=inj, want_preds=True)
+    loss_o, aux = st.loss_and_grads(x, y, noise)
+    res = res.cpu().double()
+    assert abs(float(res[0]) - float(loss_o)) <= 2e-5 * abs(float(loss_o)), (float(res[0]), float(loss_o))
+    assert abs(float(res[1]) - float(aux["kl"])) <= 2e-5 * abs(float(aux["kl"]))
+    assert abs(float(res[2]) - float(aux["loglik"])) <= 2e-5 * abs(float(aux["loglik"]))
+    assert torch.allclose(preds.cpu().double(), aux["preds"], rtol=2e-4, atol=1e-5)
+    g = eng.grad.cpu()
+    gmu = torch.cat([st.mu[s].grad.flatten() for s, _ in R.site_shapes(net)])
+    grho = torch.cat([st.rho[s].grad.flatten() for s, _ in R.site_shapes(net)])
+    assert rel_l2(g[:eng.P], gmu) < 2e-4, rel_l2(g[:eng.P], gmu)
+    assert rel_l2(g[eng.P:2 * eng.P], grho) < 2e-4, rel_l2(g[eng.P:2 * eng.P], grho)
+    # per-site check so that a small site cannot hide behind a big one
+    for s, off, num in eng.sites:
+        assert rel_l2(g[off:off + num], st.mu[s].grad) < 1e-3, ("mu", s)
+        assert rel_l2(g[eng.P + off:eng.P + off + num], st.rho[s].grad) < 1e-3, ("rho", s)
+
+
+@pytest.mark.parametrize("mode", ["lrt", "flipout", "radial"])
+def test_step_bf16x3_elbo_within_tolerance(mode):
+    """north star: ELBO within 1e-3 relative of the reference arithmetic (we hold 1e-4) at the
+    shipped hyper-parameters, batch 100."""
+    S, B = 2, 100
+    eng, cfg, st, x, y, noise, (ps, qs, lr) = _setup("inception", mode, "bf16x3", S, B)
+    inj = to_injected(eng, cfg, noise, B)
+    res, preds = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, noise=inj, want_preds=True)
+    loss_o, aux = st.loss_and_grads(x, y, noise)
+    res = res.cpu().double()
+    assert abs(float(res[0]) - float(loss_o)) <= 1e-4 * abs(float(loss_o)), (float(res[0]), float(loss_o))
+    assert torch.allclose(preds.cpu().double(), aux["preds"], rtol=2e-3, atol=1e-4)
+    g = eng.grad.cpu()
+    gmu = torch.cat([st.mu[s].grad.flatten() for s, _ in R.site_shapes("inception")])
+    grho = torch.cat([st.rho[s].grad.flatten() for s, _ in R.site_shapes("inception")])
+    assert rel_l2(g[:eng.P], gmu) < 3e-2, rel_l2(g[:eng.P], gmu)
+    assert rel_l2(g[eng.P:2 * eng.P], grho) < 0.15, rel_l2(g[eng.P:2 * eng.P], grho)
+
+
+@pytest.mark.parametrize("mode", ["lrt", "radial"])
+def test_three_adam_steps_match_oracle(mode):
+    """svi.step x3 incl. ClippedAdam on (mu, log sigma): parameters after 3 steps."""
+    S, B = 1, 9
+    eng, cfg, st, x, y, _, (ps, qs, lr) = _setup("inception", mode, "f32", S, B, q_boost=20.0)
+    from bayesrul_amd.engine import AdamHyper
+    hyp = AdamHyper(lr=lr, betas=(0.95, 0.999), clip_norm=15.0)
+    for k in range(3):
+        noise = R.make_noise(cfg, B, S, torch.Generator().manual_seed(100 + k))
+        inj = to_injected(eng, cfg, noise, B)
+        res = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, hyp, noise=inj)
+        lo, _ = st.step(x, y, noise)
+        assert abs(float(res[0]) - lo) <= 5e-5 * abs(lo), (k, float(res[0]), lo)
+    mu_o, rho_o = flat(st.mu, "inception"), flat(st.rho, "inception")
+    # Adam normalises the update to ~lr per element: compare the displacement
+    d_dev = eng.mu.cpu().double() - flat({k: v for k, v in R.init_mu0("inception", 0, torch.float64).items()}, "inception")
+    d_orc = mu_o - flat(R.init_mu0("inception", 0, torch.float64), "inception")
+    assert rel_l2(d_dev, d_orc) < 2e-2, rel_l2(d_dev, d_orc)
+    assert rel_l2(eng.rho.cpu(), rho_o) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["lrt", "flipout", "radial"])
+def test_philox_noise_replayed_in_oracle(mode):
+    """RNG mode: the kernels' own Philox noise, exported and replayed through the oracle."""
+    S, B = 2, 5
+    eng, cfg, st, x, y, _, (ps, qs, lr) = _setup("inception", mode, "f32", S, B, q_boost=20.0)
+    res = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, seed=77, step=3)
+    inj = eng.export_noise(B, S, seed=77, step=3)
+    noise = from_injected(eng, cfg, inj, B, S)
+    loss_o, aux = st.loss_and_grads(x, y, noise)
+    assert abs(float(res[0]) - float(loss_o)) <= 5e-5 * abs(float(loss_o)), (float(res[0]), float(loss_o))
+    g = eng.grad.cpu()
+    gmu = torch.cat([st.mu[s].grad.flatten() for s, _ in R.site_shapes("inception")])
+    assert rel_l2(g[:eng.P], gmu) < 5e-4
+    # the exported normals look normal
+    e = inj.eps_w.flatten().cpu()
+    assert abs(float(e.mean())) < 0.01 and abs(float(e.std()) - 1) < 0.01
+    if mode == "flipout":
+        s = torch.cat([t.flatten() for t in inj.sign_in]).cpu()
+        assert set(s.unique().tolist()) == {-1.0, 1.0} and abs(float(s.mean())) < 0.02
+
+
+def test_validation_and_kl_only_losses():
+    """evaluate_loss outside fit_ctxt (plain sampling, bayesian.py:177) and svi_no_obs (:155)."""
+    S, B = 2, 6
+    eng, cfg, st, x, y, _, (ps, qs, lr) = _setup("inception", "lrt", "f32", S, B, q_boost=20.0)
+    from bayesrul_amd import _native as N
+    noise = R.make_noise(cfg, B, S, torch.Generator().manual_seed(5), mode="normal")
+    inj = to_injected(eng, cfg, noise, B, mode="normal")
+    res, preds = eng.evaluate(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, mode=N.MODE_NORMAL, noise=inj, want_preds=True)
+    lo, aux = st.evaluate_loss(x, y, noise, mode="plain")
+    assert abs(float(res[0]) - lo) <= 2e-5 * abs(lo)
+    assert torch.allclose(preds.cpu().double(), aux["preds"], rtol=2e-4, atol=1e-5)
+    res = eng.evaluate(None, None, S, N_DATA, 0.0, ps, with_obs=False, scaled=False)
+    lo, aux = st.evaluate_loss(x, y, noise, mode="plain", obs=False, scaled=False)
+    assert abs(float(res[0]) - lo) <= 1e-5 * abs(lo)
+
+
+@pytest.mark.parametrize("guide", ["normal", "radial"])
+def test_predictive_pass_matches_oracle(guide):
+    """tasks.predict path (A16): S plain-sampled forwards + ep/al variance aggregation, with the
+    particles walked in chunks (max_windows < S*B)."""
+    S, B = 5, 11
+    mode = "radial" if guide == "radial" else "flipout"
+    ps, qs, lr = HYP[mode]
+    from bayesrul_amd.engine import SviEngine
+    eng = SviEngine(net="inception", guide=guide, fit_context="flipout" if guide == "normal" else None, prec="f32",
+                    max_particles=S, max_batch=B, max_windows=2 * B)
+    mu0 = R.init_mu0("inception", 0, torch.float64)
+    eng.init_params(mu0, qs * 50)
+    cfg = oracle_cfg("inception", "radial" if guide == "radial" else "normal", ps)
+    st = R.SviState(cfg, mu0, qs * 50, R.AdamConfig())
+    x, y = synth_batch(B)
+    noise = R.make_noise(cfg, B, S, torch.Generator().manual_seed(9))
+    inj = to_injected(eng, cfg, noise, B)
+    out4, samples = eng.predict(x.cuda(), S, noise=inj)
+    _, aux = st.evaluate_loss(x, y, noise, mode="plain")
+    ref = R.predictive_aggregate(aux["preds"])
+    assert torch.allclose(samples.cpu().double(), aux["preds"], rtol=2e-4, atol=1e-5)
+    o = out4.cpu().double()
+    assert torch.allclose(o[0], ref["preds"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(o[1], ref["stds"], rtol=1e-3, atol=1e-5)
+    assert torch.allclose(o[2], ref["ep_vars"], rtol=5e-3, atol=1e-7)
+    assert torch.allclose(o[3], ref["al_vars"], rtol=1e-4, atol=1e-6)
+
+
+def test_ragged_and_single_window_batches():
+    """B = 1 (one window) and B = 33 (dense chunk of 32 + 1) keep parity (edge cases)."""
+    for B in (1, 33):
+        S = 1
+        eng, cfg, st, x, y, noise, (ps, qs, lr) = _setup("inception", "lrt", "f32", S, B, q_boost=20.0)
+        inj = to_injected(eng, cfg, noise, B)
+        res = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, noise=inj)
+        loss_o, aux = st.loss_and_grads(x, y, noise)
+        assert abs(float(res[0]) - float(loss_o)) <= 2e-5 * abs(float(loss_o)), B
+        g = eng.grad.cpu()
+        gmu = torch.cat([st.mu[s].grad.flatten() for s, _ in R.site_shapes("inception")])
+        assert rel_l2(g[:eng.P], gmu) < 2e-4, B
+
+
+def test_full_size_properties():
+    """BASELINE sizes (S=10, B=1000): size-independent properties instead of the oracle.
+    (1) f32 and bf16x3 paths agree on the ELBO to 1e-4 on the same Philox noise;
+    (2) the step is deterministic for a fixed (seed, step) up to fp32 atomics order;
+    (3) KL is independent of the batch."""
+    S, B = 10, 1000
+    ps, qs, lr = HYP["flipout"]
+    x, y = synth_batch(B)
+    mu0 = R.init_mu0("inception", 0, torch.float64)
+    out = {}
+    for prec in ("f32", "bf16x3"):
+        eng = _engine("inception", "flipout", prec, S, B)
+        eng.init_params(mu0, qs)
+        r1 = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, seed=1, step=0).cpu().double()
+        g1 = eng.grad.cpu().clone()
+        r2 = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, seed=1, step=0).cpu().double()
+        g2 = eng.grad.cpu().clone()
+        assert abs(float(r1[0] - r2[0])) <= 1e-6 * abs(float(r1[0]))
+        assert rel_l2(g1[:eng.P], g2[:eng.P]) < 1e-4
+        out[prec] = (r1, g1)
+        del eng
+        torch.cuda.empty_cache()
+    a, b = out["f32"][0], out["bf16x3"][0]
+    assert abs(float(a[0] - b[0])) <= 1e-4 * abs(float(a[0])), (a, b)
+    assert abs(float(a[1] - b[1])) <= 1e-6 * abs(float(a[1]))
+    P = R.n_params("inception")
+    assert rel_l2(out["bf16x3"][1][:P], out["f32"][1][:P]) < 3e-2
