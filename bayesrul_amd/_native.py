@@ -22,7 +22,8 @@ EXPORTS = [
     "bnn_plan_num_params", "bnn_plan_num_sites", "bnn_plan_num_layers", "bnn_plan_workspace_bytes",
     "bnn_plan_bind", "bnn_plan_site", "bnn_plan_layer", "bnn_plan_tensor", "bnn_sample_weights",
     "bnn_forward", "bnn_head_nll", "bnn_backward", "bnn_grad_finalize", "bnn_clipped_adam",
-    "bnn_elbo_step", "bnn_elbo_evaluate", "bnn_predict", "bnn_export_noise",
+    "bnn_elbo_step", "bnn_elbo_evaluate", "bnn_predict", "bnn_export_noise", "bnn_profile_enable",
+    "bnn_profile_read",
 ]
 
 

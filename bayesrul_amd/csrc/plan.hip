@@ -51,8 +51,42 @@ struct TensorSpec {
   int alias = -1;            // shares memory with this tensor id
 };
 
+// optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<int> tag;         // kind * 16 + group
+  size_t used = 0;
+  hipEvent_t* next(int t) {
+    if (!on) return nullptr;
+    if (used + 2 > ev.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+      ev.push_back(a);
+      ev.push_back(b);
+      tag.push_back(t);
+    } else {
+      tag[used / 2] = t;
+    }
+    used += 2;
+    return &ev[used - 2];
+  }
+};
+struct ProfScope {
+  hipEvent_t* e;
+  hipStream_t st;
+  ProfScope(Prof* p, int kind, int group, hipStream_t s) : e(p ? p->next(kind * 16 + group) : nullptr), st(s) {
+    if (e) (void)hipEventRecord(e[0], st);
+  }
+  ~ProfScope() {
+    if (e) (void)hipEventRecord(e[1], st);
+  }
+};
+enum { PK_FWD = 0, PK_DX = 1, PK_DW = 2, PK_SAMPLE = 3, PK_HEAD = 4, PK_FINALIZE = 5, PK_ADAM = 6, PK_POOLBWD = 7, PK_NOISE = 8 };
+
 struct BnnPlan {
   BnnPlanDesc d;
+  Prof prof;
   int n_layers = 0, n_sites = 0, n_groups = 0;
   long P = 0;
   std::vector<std::string> site_names, layer_names;
@@ -608,6 +642,7 @@ static int do_sample(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
   A.prior_loc = (float)a->prior_loc;
   A.prior_scale = (float)a->prior_scale;
   const unsigned grid = (unsigned)((p->P + 255) / 256);
+  ProfScope ps_(&p->prof, PK_SAMPLE, 0, c->st);
   if (p->d.prec == BNN_PREC_F32)
     prep_weights_kernel<PrecF32><<<dim3(grid), dim3(256), 0, c->st>>>(A);
   else
@@ -666,8 +701,9 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
 static int img_bytes(int ch, bool bf) { return (IMG_ROWS * img_row_stride(ch, bf) * (bf ? 2 : 4) + 15) & ~15; }
 
 template <class P>
-static int launch_fwd(const GroupArgs& A0, int em, hipStream_t st) {
+static int launch_fwd(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
+  ProfScope ps_(pf, PK_FWD, gi, st);
   const int nimg = P::BF ? 3 : 2;
   A.lds_per_wave = nimg * img_bytes(DENSE_CHUNK, P::BF);
   const int lds = 4 * A.lds_per_wave;
@@ -687,8 +723,9 @@ static int launch_fwd(const GroupArgs& A0, int em, hipStream_t st) {
 }
 
 template <class P>
-static int launch_dx(const GroupArgs& A0, int em, int pool_sel, hipStream_t st) {
+static int launch_dx(const GroupArgs& A0, int em, int pool_sel, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
+  ProfScope ps_(pf, PK_DX, gi, st);
   A.pool_sel = pool_sel;
   A.lds_per_wave = 2 * img_bytes(DENSE_CHUNK, P::BF);
   const int lds = 4 * A.lds_per_wave;
@@ -708,8 +745,9 @@ static int launch_dx(const GroupArgs& A0, int em, int pool_sel, hipStream_t st) 
 }
 
 template <class P, int NW>
-static int launch_dw(const GroupArgs& A0, int em, hipStream_t st) {
+static int launch_dw(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
+  ProfScope ps_(pf, PK_DW, gi, st);
   A.lds_per_wave = 2 * img_bytes(64, P::BF) + 2 * img_bytes(DENSE_CHUNK, P::BF);
   const int lds = NW * A.lds_per_wave;
   int njobs = 0;
@@ -738,9 +776,9 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
     GroupArgs A;
     fill_group_args(p, a, c, gi, x, &A);
     if (p->d.prec == BNN_PREC_F32)
-      BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st));
+      BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else
-      BNN_TRY(launch_fwd<PrecBF>(A, c->em, c->st));
+      BNN_TRY(launch_fwd<PrecBF>(A, c->em, c->st, &p->prof, gi));
   }
   p->last_S = c->S;
   p->last_B = c->B;
@@ -757,6 +795,7 @@ static int do_head(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, float* preds,
   H.S = c->S;
   H.B = c->B;
   H.with_obs = a->with_obs && a->y;
+  ProfScope ps_(&p->prof, PK_HEAD, 0, c->st);
   head_nll_kernel<<<dim3((c->B + 255) / 256, c->S), dim3(256), 0, c->st>>>(H);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -772,9 +811,9 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
     if (p->d.prec == BNN_PREC_F32)
-      BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st)));
+      BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
     else
-      BNN_TRY((launch_dw<PrecBF, 4>(A, c->em, c->st)));
+      BNN_TRY((launch_dw<PrecBF, 4>(A, c->em, c->st, &p->prof, gi)));
     bool any_direct = false, any_pool = false;
     for (int b = 0; b < A.g.n_branch; ++b) {
       if (A.g.br[b].dx_t < 0) continue;
@@ -782,20 +821,21 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     }
     if (any_direct) {
       if (p->d.prec == BNN_PREC_F32)
-        BNN_TRY(launch_dx<PrecF32>(A, c->em, 0, c->st));
+        BNN_TRY(launch_dx<PrecF32>(A, c->em, 0, c->st, &p->prof, gi));
       else
-        BNN_TRY(launch_dx<PrecBF>(A, c->em, 0, c->st));
+        BNN_TRY(launch_dx<PrecBF>(A, c->em, 0, c->st, &p->prof, gi));
     }
     if (any_pool) {
       if (p->d.prec == BNN_PREC_F32)
-        BNN_TRY(launch_dx<PrecF32>(A, c->em, 1, c->st));
+        BNN_TRY(launch_dx<PrecF32>(A, c->em, 1, c->st, &p->prof, gi));
       else
-        BNN_TRY(launch_dx<PrecBF>(A, c->em, 1, c->st));
+        BNN_TRY(launch_dx<PrecBF>(A, c->em, 1, c->st, &p->prof, gi));
       // scatter through the arg-max of MaxPool1d(3,1,1) into the direct gradient
       const int tin = A.g.in_t;
       const long nwin = (long)c->S * c->B;
       const int C = p->tens[tin].ctot, L = A.g.L;
       const long n = nwin * L * C;
+      ProfScope ps_(&p->prof, PK_POOLBWD, gi, c->st);
       pool_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(
           tens_ptr(p, tin, 0), ws_f(p, p->o_poolgrad), tens_ptr(p, tin, 1), nwin, L, C);
       HIP_TRY(hipGetLastError());
@@ -826,6 +866,7 @@ static int do_finalize(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   F.prior_loc = (float)a->prior_loc;
   F.prior_scale = (float)a->prior_scale;
   F.grad = p->bufs.grad;
+  ProfScope ps_(&p->prof, PK_FINALIZE, 0, c->st);
   grad_finalize_kernel<<<dim3((unsigned)((p->P + 255) / 256)), dim3(256), 0, c->st>>>(F);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -869,6 +910,7 @@ static int do_adam(BnnPlan* p, const BnnAdamArgs* ad, hipStream_t st) {
   const double bc2 = 1.0 - std::pow(ad->beta2, (double)ad->step);
   A.step_size = (float)(ad->lr * std::sqrt(bc2) / bc1);
   A.grad_scale = (float)(ad->grad_scale == 0.0 ? 1.0 : ad->grad_scale);
+  ProfScope ps_(&p->prof, PK_ADAM, 0, st);
   clipped_adam_kernel<<<dim3((unsigned)((2 * p->P + 255) / 256)), dim3(256), 0, st>>>(A);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1045,5 +1087,44 @@ extern "C" int bnn_export_noise(BnnPlan* p, const BnnElboArgs* a, uint64_t seed,
     }
   }
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-kernel timing (HIP events on the launch stream)
+// ------------------------------------------------------------------------------------------
+extern "C" int bnn_profile_enable(BnnPlan* p, int on) {
+  if (!p) return fail(BNN_E_INVALID, "null plan");
+  p->prof.on = on != 0;
+  p->prof.used = 0;
+  return 0;
+}
+
+// Synchronises the recorded events and returns, per (kind, group) tag, the summed duration in
+// milliseconds and the launch count.  tags/ms/count must hold `cap` entries; *n receives the
+// number of distinct tags.  Resets the recorder.
+extern "C" int bnn_profile_read(BnnPlan* p, int32_t* tags, double* ms, int64_t* count, int32_t cap, int32_t* n) {
+  if (!p || !tags || !ms || !count || !n) return fail(BNN_E_INVALID, "null argument");
+  int m = 0;
+  for (size_t k = 0; k + 1 < p->prof.used; k += 2) {
+    HIP_TRY(hipEventSynchronize(p->prof.ev[k + 1]));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, p->prof.ev[k], p->prof.ev[k + 1]));
+    const int tg = p->prof.tag[k / 2];
+    int j = 0;
+    for (; j < m; ++j)
+      if (tags[j] == tg) break;
+    if (j == m) {
+      if (m >= cap) return fail(BNN_E_INVALID, "profile table too small");
+      tags[m] = tg;
+      ms[m] = 0;
+      count[m] = 0;
+      ++m;
+    }
+    ms[j] += t;
+    count[j] += 1;
+  }
+  *n = m;
+  p->prof.used = 0;
   return 0;
 }

@@ -329,6 +329,17 @@ class SviEngine:
                                               a1, a2, a3, C.c_void_p(self._stream())))
         return out
 
+    def profile(self, on: bool) -> None:
+        N.check(self.lib.bnn_profile_enable(self._plan, int(on)))
+
+    def profile_read(self) -> Dict[Tuple[str, int], Tuple[float, int]]:
+        """{(kind, group): (total ms, launches)} since the last read (HIP events on the stream)."""
+        cap = 256
+        tags, ms, cnt, n = (C.c_int32 * cap)(), (C.c_double * cap)(), (C.c_int64 * cap)(), C.c_int32()
+        N.check(self.lib.bnn_profile_read(self._plan, tags, ms, cnt, cap, C.byref(n)))
+        kinds = ["fwd", "dx", "dw", "sample", "head", "finalize", "adam", "pool_bwd", "noise"]
+        return {(kinds[tags[i] // 16], tags[i] % 16): (ms[i], cnt[i]) for i in range(n.value)}
+
     def tensor(self, which: int) -> torch.Tensor:
         """Copy of an intermediate activation of the last forward (tests)."""
         p, rows, ct = C.c_void_p(), C.c_int64(), C.c_int32()

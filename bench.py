@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — ELBO-step MC-samples x windows / sec of the MI355X SVI/ELBO path.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run,
+one rank per GPU, RCCL).  A step = one full svi.step over one batch of synthetic
+N-CMAPSS-shaped windows: sample -> forward -> NLL -> backward -> [all-reduce] -> ClippedAdam.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# hyper-parameters: bayesrul/conf/experiment/ncmapss_{lrt,fo,rad}.yaml:17-25
+WORKLOADS = {
+    # BASELINE.json configs[2]: Flipout BNN (Conv1d net), 10 MC samples
+    "flipout_conv_s10": dict(net="inception", guide="normal", fit_context="flipout", S=10, B=1000,
+                             prior_scale=0.198768, q_scale=0.000214, lr=9.48e-4),
+    # configs[3]: Radial BNN (Conv1d net), 20 MC samples, batch-DP
+    "radial_conv_s20": dict(net="inception", guide="radial", fit_context=None, S=20, B=1000,
+                            prior_scale=0.092516, q_scale=0.001241, lr=9.56e-4),
+    # configs[1]: LRT BNN (Linear net), 1 MC sample
+    "lrt_linear_s1": dict(net="linear", guide="normal", fit_context="lrt", S=1, B=1000,
+                          prior_scale=0.138793, q_scale=0.001351, lr=8.57e-4),
+    "lrt_conv_s1": dict(net="inception", guide="normal", fit_context="lrt", S=1, B=1000,
+                        prior_scale=0.138793, q_scale=0.001351, lr=8.57e-4),
+}
+N_DATA = 238200
+
+# algorithmic MACs per sample-window of each branch group; 1 MAC = 2 FLOP
+GROUP_MACS = {
+    "inception": [30 * 27 * (18 + 54 + 90 + 54), 30 * 108 * (16 + 64 + 64 + 32), 30 * (192 * 16 + 320 * 16),
+                  2400 * 64, 64 * 2],
+    "linear": [540 * 256, 256 * 128, 128 * 128, 128 * 32, 32 * 2],
+}
+# which groups produce a dX (group 0 reads the input windows: no dX)
+PEAK_TFLOPS = {"bf16x3": 2500.0, "f32": 157.3}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def synth(B_total, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B_total, 30, 18, generator=g)
+    y = torch.randint(0, 100, (B_total,), generator=g).float()
+    return x, y
+
+
+def mu0_for(net):
+    """Seeded init with the reference's initialisers (utils/miscellaneous.py:53-63): xavier-normal
+    conv / kaiming-normal linear weights, torch-default biases."""
+    import math
+    from bayesrul_amd.models.nets.spec import net_layers
+    g = torch.Generator().manual_seed(0)
+    out = {}
+    for name, conv, cout, cin, k in net_layers(net):
+        if conv:
+            std = math.sqrt(2.0 / (cin * k + cout * k))
+            w = torch.randn(cout, cin, k, generator=g) * std
+            fan_in = cin * k
+        else:
+            w = torch.randn(cout, cin, generator=g) * math.sqrt(2.0 / cin)
+            fan_in = cin
+        out[name + ".weight"] = w
+        out[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) / math.sqrt(fan_in)
+    return out
+
+
+def cpu_baseline(wl, seconds_target=15.0):
+    """CPU restatement of the reference path (oracle/, kind 'port') timed on this box's host
+    cores: fp32, sequential particle loop, per-layer F.conv1d / F.linear, autograd, ClippedAdam."""
+    from oracle import restatement as R
+    # the 1-GPU box grants a 16-core CPU share; more threads than that only oversubscribes
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
+    B, S = 100, wl["S"]
+    cfg = R.ElboConfig(net=wl["net"], guide=wl["guide"], fit_context=wl["fit_context"], dataset_size=N_DATA,
+                       prior_scale=wl["prior_scale"])
+    st = R.SviState(cfg, R.init_mu0(wl["net"], 0, torch.float32), wl["q_scale"], R.AdamConfig(lr=wl["lr"]),
+                    dtype=torch.float32)
+    x, y = synth(B)
+    gen = torch.Generator().manual_seed(4321)
+    noise = R.make_noise(cfg, B, S, gen, dtype=torch.float32)
+    st.step(x, y, noise)  # warm-up
+    n, t0 = 0, time.time()
+    while True:
+        st.step(x, y, noise)
+        n += 1
+        if time.time() - t0 > seconds_target or n >= 100:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": S * B / dt, "unit": "MC-samples*windows/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of B={B}, S={S}, fp32 torch CPU restatement ({dt * 1e3:.1f} ms/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="flipout_conv_s10", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: workload's)")
+    ap.add_argument("--prec", default="bf16x3", choices=["bf16x3", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from bayesrul_amd.engine import AdamHyper, SviEngine
+    from bayesrul_amd.parallel import dp_step
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"] = args.batch
+    S, B = wl["S"], wl["B"]
+    eng = SviEngine(net=wl["net"], guide=wl["guide"], fit_context=wl["fit_context"], prec=args.prec, max_particles=S,
+                    max_batch=B, device=dev)
+    eng.init_params(mu0_for(wl["net"]), wl["q_scale"])
+    xg, yg = synth(B * world)
+    x = xg[rank * B:(rank + 1) * B].contiguous().to(dev)
+    y = yg[rank * B:(rank + 1) * B].contiguous().to(dev)
+    hyp = AdamHyper(lr=wl["lr"], betas=(0.95, 0.999), clip_norm=15.0)
+
+    def one_step():
+        if world > 1:
+            return dp_step(eng, x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, rank, world, seed=4321)
+        return eng.step(x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, seed=4321)
+
+    for _ in range(args.warmup):
+        res = one_step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(res[0])
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = S * B * world / (dt / args.steps)
+        # dominant kernel = the kernel SYMBOL (group_fwd / group_dx / group_dw; one symbol serves
+        # all branch groups) with the largest summed duration inside the timed region.  Its
+        # algorithmic FLOPs per launch = (sum over its launches of 2*MAC*contractions*S*B) / launches,
+        # so achieved = total algorithmic FLOPs / total time = FLOPs-per-launch / average duration.
+        ncontr = 2 if wl["fit_context"] in ("lrt", "flipout") else 1
+        macs = GROUP_MACS[wl["net"]]
+        agg = {}
+        for (kind, grp), (tot_ms, cnt) in prof.items():
+            if kind not in ("fwd", "dx", "dw"):
+                continue
+            a = agg.setdefault(kind, [0.0, 0, 0.0])
+            a[0] += tot_ms
+            a[1] += cnt
+            a[2] += 2.0 * macs[grp] * ncontr * S * B * args.steps  # dx[1] runs as 2 launches (direct + pooled)
+        kind, (tot_ms, cnt, flops_tot) = max(agg.items(), key=lambda kv: kv[1][0])
+        flops_launch = flops_tot / cnt
+        avg_s = tot_ms / cnt * 1e-3
+        achieved = flops_launch / avg_s / 1e12
+        peak = PEAK_TFLOPS[args.prec]
+        sym = {"fwd": "group_fwd_kernel", "dx": "group_dx_kernel", "dw": "group_dw_kernel"}[kind]
+        kernels = {f"{k[0]}[{k[1]}]": round(v[0] / args.steps, 4) for k, v in sorted(prof.items())}
+        out = {
+            "metric": "ELBO-step MC-samples x windows/sec, Conv BNN on N-CMAPSS",
+            "value": value, "unit": "MC-samples*windows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+            "config": {"workload": args.workload, "net": wl["net"], "estimator": wl["fit_context"] or wl["guide"],
+                       "mc_samples": S, "windows_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}", "loss": loss},
+            "roofline": {"bound": "mfma", "kernel": sym, "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "avg_launch_us": avg_s * 1e6, "flops_per_launch": flops_launch,
+                         "launches_per_step": cnt / args.steps},
+            "kernel_ms_per_step": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

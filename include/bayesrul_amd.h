@@ -179,6 +179,12 @@ int bnn_export_noise(BnnPlan* plan, const BnnElboArgs* a, uint64_t seed, uint64_
                      float* radial_r, float* const* lrt_eps, float* const* sign_in, float* const* sign_out,
                      void* stream);
 
+/* ---- measurement: per-kernel durations from HIP events recorded on the launch stream ----
+ * tag = kind * 16 + group; kind: 0 group forward, 1 group dX, 2 group dW, 3 weight sampling,
+ * 4 head/NLL, 5 gradient finalize, 6 ClippedAdam, 7 max-pool backward. */
+int bnn_profile_enable(BnnPlan* plan, int on);
+int bnn_profile_read(BnnPlan* plan, int32_t* tags, double* ms, int64_t* count, int32_t cap, int32_t* n);
+
 #ifdef __cplusplus
 }
 #endif
