@@ -1,0 +1,221 @@
+"""`BNN` — drop-in for `bayesrul.models.bayesian.BNN` (bayesrul/models/bayesian.py:20-264).
+
+Same constructor keywords, hook names, logged keys and `predict_step` dictionary; the Pyro /
+TyXe machinery the reference wires together per step (SVI, TraceMeanField_ELBO / Trace_ELBO,
+VariationalBNN, the LRT / Flipout messengers, ClippedAdam) is replaced by ONE call into the
+MI355X kernels per batch (`SviEngine.step`).  Differences, all deliberate:
+  * `optimizer` is the ClippedAdam argument dict of conf/model/bnn.yaml:6-10 (or an AdamHyper),
+    not a pyro.optim object (Pyro is not a dependency);
+  * the by-products the reference obtains from 2*S extra no-grad forwards per training step
+    (`bnn.predict`, `svi_no_obs.evaluate_loss`, bayesian.py:149-155) come out of the same step:
+    predictions of the S training particles and the KL term of the loss;
+  * no per-step host synchronisation: logged values stay on the device until the epoch ends;
+  * the variational means are always initialised from `net` (the reference does so only for
+    `pretrain_epochs > 0`; its default `init_to_median` draw is not reproducible, U11).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from ..engine import AdamHyper, SviEngine
+from ..results.metrics import rms_calibration_error, sharpness
+from ..utils.miscellaneous import weights_init
+from .guides.auto import AutoNormal, AutoRadial
+
+try:  # pragma: no cover - Lightning is optional
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover
+    from ..lightning_lite import LightningModuleLite as _Base
+
+
+def _adam_hyper(optimizer) -> AdamHyper:
+    if isinstance(optimizer, AdamHyper):
+        return optimizer
+    if isinstance(optimizer, dict):
+        d = dict(optimizer)
+        return AdamHyper(lr=d.get("lr", 1e-3), betas=tuple(d.get("betas", (0.9, 0.999))), eps=d.get("eps", 1e-8),
+                         clip_norm=d.get("clip_norm", 10.0), lrd=d.get("lrd", 1.0),
+                         weight_decay=d.get("weight_decay", 0.0))
+    raise RuntimeError("optimizer must be the ClippedAdam argument dict {lr, betas, clip_norm, ...} or an AdamHyper")
+
+
+def aggregate_predictions(preds: torch.Tensor) -> torch.Tensor:
+    """HeteroskedasticGaussian.aggregate_predictions (U4): precision-weighted mean and
+    sqrt(mean(s^2) + var(loc)) over particles; preds [S,B,2] are net outputs, the likelihood's
+    softplus is applied to the scale column (positive_scale=False, bayesian.py:73-76)."""
+    loc, scale = preds[..., 0], F.softplus(preds[..., 1])
+    prec = scale.pow(-2)
+    agg_loc = (loc * prec).sum(0) / prec.sum(0)
+    agg_scale = (scale.pow(2).mean(0) + loc.var(0)).sqrt()
+    return torch.stack([agg_loc, agg_scale], -1)
+
+
+class VariationalBNN:
+    """What the reference reaches through `self.bnn` (tyxe.bnn.VariationalBNN): predict() and
+    the guide."""
+
+    def __init__(self, engine: SviEngine, guide):
+        self.engine, self.net_guide = engine, guide
+        self.guide = guide
+        self._calls = 0
+
+    def predict(self, x, num_predictions=1, aggregate=True, seed: int = 0):
+        self._calls += 1
+        _, samples = self.engine.predict(x.contiguous().float(), num_predictions, seed=seed, step=self._calls)
+        return aggregate_predictions(samples) if aggregate else samples
+
+
+class BNN(_Base):
+    def __init__(self, net: torch.nn.Module, optimizer, pretrain_epochs: int, mc_samples_train: int,
+                 mc_samples_eval: int, dataset_size: int, fit_context: Optional[str], prior_loc: float,
+                 prior_scale: float, guide: str, q_scale: float, prec: str = "bf16x3", max_batch: int = 1000,
+                 max_eval_batch: int = 10000, seed: int = 0):
+        super().__init__()
+        self.save_hyperparameters(logger=False, ignore=["net"])
+        self.net = net
+        self.engine: Optional[SviEngine] = None
+
+    # ---- bayesian.py:45-98
+    def define_bnn(self) -> None:
+        hp = self.hparams
+        if not hp.pretrain_epochs == 0:
+            self.net.apply(weights_init)  # sic: the reference re-initialises here
+        if hp.guide not in ("normal", "radial"):
+            raise RuntimeError("Guide unknown. Choose from 'normal', 'radial'.")
+        kind = type(self.net).__name__.lower()
+        net_kind = "inception" if "inception" in kind else "linear"
+        if not hasattr(self.net, "win_length"):
+            raise AttributeError("net must carry win_length / n_features (bayesian.py:117-118)")
+        S = max(hp.mc_samples_train, hp.mc_samples_eval)
+        B = max(hp.max_batch, 1)
+        eval_windows = max(S * B, min(hp.mc_samples_eval * hp.max_eval_batch, 200_000))
+        self.engine = SviEngine(net=net_kind, guide=hp.guide, fit_context=hp.fit_context, prec=hp.prec, max_particles=S,
+                                max_batch=max(B, hp.max_eval_batch), win_length=self.net.win_length,
+                                n_features=self.net.n_features, device=self.device, max_windows=eval_windows)
+        mu0 = {k: v.detach() for k, v in copy.deepcopy(self.net).state_dict().items()}
+        self.engine.init_params(mu0, hp.q_scale)
+        if getattr(self, "_pending_param_store", None) is not None:
+            self._restore_param_store(self._pending_param_store)
+            self._pending_param_store = None
+        guide_cls = AutoNormal if hp.guide == "normal" else AutoRadial
+        self.bnn = VariationalBNN(self.engine, guide_cls(self.engine, init_scale=hp.q_scale))
+        self.adam = _adam_hyper(hp.optimizer)
+
+    # ---- bayesian.py:100-132
+    def on_fit_start(self) -> None:
+        self.define_bnn()
+        self.configure_optimizers()
+
+    def _metrics(self, loc, scale, y):
+        return F.mse_loss(y, loc), rms_calibration_error(loc, scale, y), sharpness(scale)
+
+    # ---- bayesian.py:134-166
+    def training_step(self, batch, batch_idx):
+        x, y = batch[0].contiguous().float(), batch[1].contiguous().float().reshape(-1)
+        hp = self.hparams
+        S = hp.mc_samples_train
+        res, preds = self.engine.step(x, y, S, hp.dataset_size, hp.prior_loc, hp.prior_scale, self.adam,
+                                      seed=hp.seed, want_preds=True)
+        elbo, kl = res[0], res[1]
+        output = aggregate_predictions(preds) if S > 1 else preds[0]
+        loc, scale = output[:, 0], output[:, 1]
+        mse, rmsce, sharp = self._metrics(loc, scale, y)
+        self.log("mse/train", mse, on_step=False, on_epoch=True)
+        self.log("elbo/train", elbo, on_step=False, on_epoch=True)
+        self.log("kl/train", kl, on_step=False, on_epoch=True)
+        self.log("likelihood/train", elbo - kl, on_step=False, on_epoch=True)
+        self.log("rmsce/train", rmsce, on_step=False, on_epoch=True)
+        self.log("sharp/train", sharp, on_step=False, on_epoch=True)
+
+    # ---- bayesian.py:168-197 (validation runs outside fit_ctxt: plain sampling)
+    def validation_step(self, batch, batch_idx):
+        x, y = batch[0].contiguous().float(), batch[1].contiguous().float().reshape(-1)
+        hp = self.hparams
+        res = self.engine.evaluate(x, y, hp.mc_samples_train, hp.dataset_size, hp.prior_loc, hp.prior_scale,
+                                   mode=self.engine.plain_mode(), seed=hp.seed + 1, step=batch_idx)
+        elbo = res[0]
+        output = self.bnn.predict(x, num_predictions=hp.mc_samples_eval, aggregate=hp.mc_samples_eval > 1,
+                                  seed=hp.seed + 2)
+        output = output if output.dim() == 2 else output[0]
+        loc, scale = output[:, 0], output[:, 1]
+        kl = self.engine.evaluate(None, None, hp.mc_samples_train, hp.dataset_size, hp.prior_loc, hp.prior_scale,
+                                  mode=self.engine.plain_mode(), with_obs=False, scaled=False, seed=hp.seed + 3,
+                                  step=batch_idx)[0]
+        mse, rmsce, sharp = self._metrics(loc, scale, y)
+        self.log("elbo/val", elbo)
+        self.log("mse/val", mse)
+        self.log("kl/val", kl)
+        self.log("likelihood/val", elbo - kl)
+        self.log("rmsce/val", rmsce)
+        self.log("sharp/val", sharp)
+
+    def on_test_start(self) -> None:
+        self.define_bnn()
+
+    def _predictive(self, x):
+        out4, _ = self.engine.predict(x.contiguous().float(), self.hparams.mc_samples_eval, seed=self.hparams.seed + 4,
+                                      step=getattr(self, "_pred_calls", 0), want_samples=False)
+        self._pred_calls = getattr(self, "_pred_calls", 0) + 1
+        return out4  # preds, stds, ep_vars, al_vars
+
+    # ---- bayesian.py:203-225
+    def test_step(self, batch, batch_idx):
+        x, y = batch[0], batch[1].contiguous().float().reshape(-1)
+        out4 = self._predictive(x)
+        loc, scale = out4[0], out4[1]
+        nll = F.gaussian_nll_loss(loc, y, torch.square(scale))
+        mse, rmsce, sharp = self._metrics(loc, scale, y)
+        self.log("nll/test", nll)
+        self.log("mse/test", mse)
+        self.log("rmsce/test", rmsce)
+        self.log("sharp/test", sharp)
+        return nll
+
+    def on_predict_start(self) -> None:
+        self.define_bnn()
+
+    # ---- bayesian.py:231-250
+    def predict_step(self, batch, batch_idx, dataloader_idx=0):
+        out4 = self._predictive(batch[0])
+        return {"labels": batch[1].cpu().numpy(), "ep_vars": out4[2].cpu().numpy(), "al_vars": out4[3].cpu().numpy(),
+                "preds": out4[0].cpu().numpy(), "stds": out4[1].cpu().numpy()}
+
+    def configure_optimizers(self):
+        return None
+
+    # ---- bayesian.py:255-264: Pyro-param-store shaped entry (names unverified, U12)
+    def on_save_checkpoint(self, checkpoint: Dict) -> None:
+        params, eng = {}, self.engine
+        for name, _, _ in eng.sites:
+            params[f"net_guide.{name}.loc"] = eng.loc(name).detach().cpu().clone()
+            params[f"net_guide.{name}.scale"] = eng.log_scale(name).detach().cpu().clone()  # unconstrained
+        checkpoint["param_store"] = {"params": params, "constraints": {k: "positive" if k.endswith(".scale") else "real"
+                                                                        for k in params}}
+        checkpoint["svi_engine"] = eng.state_dict()
+
+    def _restore_param_store(self, store: Dict) -> None:
+        eng = self.engine
+        with torch.no_grad():
+            for name, _, _ in eng.sites:
+                eng.loc(name).copy_(store["params"][f"net_guide.{name}.loc"].to(eng.device))
+                eng.log_scale(name).copy_(store["params"][f"net_guide.{name}.scale"].to(eng.device))
+
+    def on_load_checkpoint(self, checkpoint: Dict) -> None:
+        if self.engine is None:  # restored when define_bnn builds the engine (on_*_start)
+            self._pending_param_store = checkpoint["param_store"]
+        else:
+            self._restore_param_store(checkpoint["param_store"])
+            if "svi_engine" in checkpoint:
+                self.engine.load_state_dict(checkpoint["svi_engine"])
+        if not hasattr(self, "bnn"):
+            checkpoint["state_dict"] = remove_dict_entry_startswith(checkpoint["state_dict"], "bnn")
+
+
+def remove_dict_entry_startswith(dictionary, string):
+    """bayesian.py:274-282"""
+    return {k: v for k, v in dictionary.items() if not k.startswith(string)}

@@ -211,3 +211,41 @@ def test_full_size_properties():
     assert abs(float(a[1] - b[1])) <= 1e-6 * abs(float(a[1]))
     P = R.n_params("inception")
     assert rel_l2(out["bf16x3"][1][:P], out["f32"][1][:P]) < 3e-2
+
+
+def test_dp_noise_is_rank_invariant():
+    """The Philox noise of a shard [off, off+B) of a global batch equals the slice of the
+    noise of the whole batch (per-window streams are indexed by the GLOBAL window id) and the
+    weight-level noise is identical on every rank."""
+    S, Bg, B = 2, 8, 4
+    for mode in ("lrt", "flipout", "radial"):
+        eng = _engine("inception", mode, "f32", S, Bg)
+        full = eng.export_noise(Bg, S, seed=5, step=9)
+        for off in (0, 4):
+            part = eng.export_noise(B, S, seed=5, step=9, global_batch=Bg, global_batch_offset=off)
+            assert torch.equal(part.eps_w, full.eps_w) and torch.equal(part.radial_r, full.radial_r)
+            for li in range(eng.n_layers):
+                assert torch.equal(part.lrt_eps[li], full.lrt_eps[li][:, off:off + B]), (mode, li)
+                assert torch.equal(part.sign_in[li], full.sign_in[li][:, off:off + B])
+                assert torch.equal(part.sign_out[li], full.sign_out[li][:, off:off + B])
+        del eng
+
+
+def test_dp_two_shards_equal_global_step():
+    """1 GPU on the global batch == mean of two shard steps (what 2 ranks + all-reduce compute)."""
+    S, Bg = 2, 8
+    ps, qs, lr = HYP["flipout"]
+    x, y = synth_batch(Bg)
+    mu0 = R.init_mu0("inception", 0, torch.float64)
+    eng = _engine("inception", "flipout", "f32", S, Bg)
+    eng.init_params(mu0, qs * 20)
+    eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, seed=3, step=1)
+    g_full = eng.grad.cpu().clone()
+    acc = torch.zeros_like(g_full)
+    for off in (0, 4):
+        eng.step(x[off:off + 4].contiguous().cuda(), y[off:off + 4].contiguous().cuda(), S, N_DATA, 0.0, ps, None,
+                 seed=3, step=1, global_batch=Bg, global_batch_offset=off)
+        acc += eng.grad.cpu()
+    acc /= 2
+    assert rel_l2(acc[:-2], g_full[:-2]) < 1e-5
+    assert abs(float(acc[-2] - g_full[-2])) < 1e-5 * abs(float(g_full[-2]))
