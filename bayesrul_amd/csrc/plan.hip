@@ -14,6 +14,7 @@
 #include "../../include/bayesrul_amd.h"
 #include "kernels_group.h"
 #include "kernels_misc.h"
+#include "kernels_conv_bf.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -771,6 +772,66 @@ static int launch_dw(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int 
   return 0;
 }
 
+// ---- round-1 optimised bf16 conv-group kernels (kernels_conv_bf.h) ----
+static void build_conv_dw_plan(const GroupArgs& A, const LayerDesc* layers, ConvDwPlan* D) {
+  *D = ConvDwPlan{};
+  int zo = 0, nt = 0;
+  for (int b = 0; b < A.g.n_branch; ++b) {
+    const BranchDesc& br = A.g.br[b];
+    const LayerDesc& ly = layers[br.layer];
+    D->zoff[b] = zo;
+    zo += (br.cout + 15) & ~15;
+    if (br.pool) D->has_pool = 1;
+    const int ctiles = (br.cin_p + 15) / 16;
+    for (int n = 0; n < br.ntiles; ++n)
+      for (int t = 0; t < ly.taps; ++t)
+        for (int c = 0; c < ctiles; ++c) {
+          DwTile T;
+          T.b = (signed char)b; T.nt = (signed char)n; T.tap = (signed char)t; T.ct = (signed char)c;
+          D->tile[nt++] = T;
+        }
+  }
+  D->ntiles = nt;
+  D->zw = zo;
+}
+
+template <int EM>
+static int launch_conv_dw_bf_em(const GroupArgs& A, const ConvDwPlan& D, int lds, unsigned grid, hipStream_t st) {
+  const int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
+  if (tpw <= 4) {
+    BNN_TRY(set_lds(conv_dw_bf_kernel<EM, 4, 2, 3>, lds));
+    conv_dw_bf_kernel<EM, 4, 2, 3><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+  } else if (tpw <= 6) {
+    BNN_TRY(set_lds(conv_dw_bf_kernel<EM, 6, 2, 3>, lds));
+    conv_dw_bf_kernel<EM, 6, 2, 3><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+  } else {
+    BNN_TRY(set_lds(conv_dw_bf_kernel<EM, 10, 2, 3>, lds));
+    conv_dw_bf_kernel<EM, 10, 2, 3><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_conv_dw_bf(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  ConvDwPlan D;
+  build_conv_dw_plan(A, layers, &D);
+  if (D.ntiles > 96 || (D.ntiles + CV_WAVES - 1) / CV_WAVES > 10) return fail(BNN_E_INVALID, "conv dW plan too large");
+  D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+  const int xw16 = rup(A.g.in_cin_p, 16);
+  const int xbytes = (IMG_ROWS * img_row_stride(xw16, true) * 2 + 15) & ~15;
+  const int zbytes = (IMG_ROWS * img_row_stride(D.zw, true) * 2 + 15) & ~15;
+  const int lds = 4 * xbytes + 2 * zbytes;
+  const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
+  // staging-unit capacity of the instantiations: XU = 2, ZU = 3 float4 per thread
+  if (A.g.L * (A.g.in_cin_p / 4) > 2 * CV_THREADS || A.g.L * (D.zw / 4) > 3 * CV_THREADS)
+    return fail(BNN_E_INVALID, "conv dW staging plan exceeds the compiled unit counts");
+  ProfScope ps_(pf, PK_DW, gi, st);
+  if (em == EM_PLAIN) return launch_conv_dw_bf_em<EM_PLAIN>(A, D, lds, grid, st);
+  if (em == EM_LRT) return launch_conv_dw_bf_em<EM_LRT>(A, D, lds, grid, st);
+  return launch_conv_dw_bf_em<EM_FLIPOUT>(A, D, lds, grid, st);
+}
+
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   for (int gi = 0; gi < p->n_groups; ++gi) {
     GroupArgs A;
@@ -812,6 +873,8 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     fill_group_args(p, a, c, gi, a->x, &A);
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
+    else if (!A.g.is_dense)
+      BNN_TRY(launch_conv_dw_bf(A, p->layers, c->em, c->st, &p->prof, gi));
     else
       BNN_TRY((launch_dw<PrecBF, 4>(A, c->em, c->st, &p->prof, gi)));
     bool any_direct = false, any_pool = false;
