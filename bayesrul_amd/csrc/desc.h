@@ -14,10 +14,14 @@ enum { DENSE_CHUNK = 128 };  // channels per K-chunk of a dense layer (and of a 
 // estimator of a contraction (kernel template parameter)
 enum { EM_PLAIN = 0, EM_LRT = 1, EM_FLIPOUT = 2 };
 
+// fmt 0: fp32 rows in `p`.  fmt 1: bf16 planes, `p` = hi plane, `lo` = lo plane (value = hi + lo;
+// nullptr: single bf16 plane).  Row stride = ctot elements in every plane.
+enum { TF_F32 = 0, TF_BF16 = 1 };
 struct TensorRef {
-  float* p;
-  int ctot;  // channels per row (row stride, floats)
-  int pad_;
+  void* p;
+  void* lo;
+  int ctot;  // channels per row (row stride, elements)
+  int fmt;
 };
 
 // How a layer's canonical input-channel index maps to the image channel index of its input

@@ -82,16 +82,14 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs 
     if (c + 4 > tin.ctot && x_ok[u]) x_ok[u] = (c < tin.ctot);  // partial handled in loader
   }
   int z_src[ZU], z_dst[ZU], z_nv[ZU];
-  const float* z_g[ZU];   // dY tensor base
-  const float* z_y[ZU];   // Y (relu mask) tensor base or null
-  const float* z_q[ZU];   // q tensor base (LRT)
+  int z_tg[ZU], z_ty[ZU], z_tq[ZU];   // tensor ids of dY / Y (relu mask; -1 none) / q (LRT)
   int z_ct[ZU];
 #pragma unroll
   for (int u = 0; u < ZU; ++u) {
     const int unit = tid + u * CV_THREADS;
     z_nv[u] = 0;
     z_src[u] = z_dst[u] = z_ct[u] = 0;
-    z_g[u] = z_y[u] = z_q[u] = nullptr;
+    z_tg[u] = z_ty[u] = z_tq[u] = -1;
     if (unit < zunits) {
       const int row = unit / zc4, zc = (unit - row * zc4) * 4;
       int b = 0;
@@ -106,9 +104,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs 
         z_ct[u] = tg.ctot;
         z_src[u] = row * tg.ctot + br.out_off + c;
         z_dst[u] = (row + HALO) * RSz + zc;
-        z_g[u] = tg.p;
-        z_y[u] = br.relu ? A.t[br.out_t].p : nullptr;
-        z_q[u] = LRT ? A.t[br.q_t].p : nullptr;
+        z_tg[u] = br.out_t + T_GRAD;
+        z_ty[u] = br.relu ? br.out_t : -1;
+        z_tq[u] = LRT ? br.q_t : -1;
       }
     }
   }
@@ -163,9 +161,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs 
     for (int u = 0; u < XU; ++u) {
       px[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (x_ok[u]) {
-        const float* p = tin.p + xrow0 * tin.ctot + x_src[u];
         const int c = x_src[u] % tin.ctot;
-        px[u] = load4(p, tin.ctot - c, x_vec);
+        px[u] = tload4(tin, xrow0 * tin.ctot + x_src[u], tin.ctot - c, x_vec);
       }
     }
 #pragma unroll
@@ -175,14 +172,14 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs 
       if (z_nv[u] > 0) {
         const long o = zrow0 * z_ct[u] + z_src[u];
         const bool v = ((z_ct[u] & 3) == 0) && ((z_src[u] & 3) == 0);
-        f32x4 g = load4(z_g[u] + o, z_nv[u], v);
-        if (z_y[u]) {
-          const f32x4 y = load4(z_y[u] + o, z_nv[u], v);
+        f32x4 g = tload4(A.t[z_tg[u]], o, z_nv[u], v);
+        if (z_ty[u] >= 0) {
+          const f32x4 y = tload4(A.t[z_ty[u]], o, z_nv[u], v);
 #pragma unroll
           for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
         }
         pz[u] = g;
-        if constexpr (LRT) pq[u] = load4(z_q[u] + o, z_nv[u], v);
+        if constexpr (LRT) pq[u] = tload4(A.t[z_tq[u]], o, z_nv[u], v);
       }
     }
     if constexpr (EM == EM_FLIPOUT) {

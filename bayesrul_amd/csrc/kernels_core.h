@@ -78,15 +78,16 @@ __device__ __forceinline__ long global_row(const CallGeom& cg, int L, int R) {
 enum { SEC_NONE = 0, SEC_SQUARE = 1, SEC_SIGN = 2, SEC_MUL = 3 };
 
 struct StageSpec {
-  const float* src;   // row 0 of the window in the source tensor
+  TensorRef src;      // source tensor
+  long row0;          // row 0 of the window in the source / mask / mul tensors
   int ctot;           // source row stride
   int coff;           // first source channel
   int cw;             // real channels available from coff (rest of cwp is zero)
   int cwp;            // image channels (multiple of 8)
   int nvalid;         // valid rows
   int pool;           // MaxPool1d(3,1,1) of the source
-  const float* mask;  // relu mask source (same geometry as src) or nullptr
-  const float* mul;   // SEC_MUL: multiplier tensor (same geometry as src)
+  TensorRef mask;     // relu mask source (same geometry as src); mask.p == nullptr: none
+  TensorRef mul;      // SEC_MUL: multiplier tensor (same geometry as src)
   const uint32_t* sign;  // SEC_SIGN: packed sign words of example 0 of this window
   int sign_stride;       // words per example
   int sign_per_row;      // 1: example = row (dense); 0: example = window (conv)
@@ -106,6 +107,69 @@ __device__ __forceinline__ f32x4 load4(const float* p, int nvalid_c, bool vec_ok
   return v;
 }
 
+__device__ __forceinline__ f32x4 unpack_bf4(uint2 h) {
+  f32x4 v;
+  v[0] = bf2f((u16)(h.x & 0xffff));
+  v[1] = bf2f((u16)(h.x >> 16));
+  v[2] = bf2f((u16)(h.y & 0xffff));
+  v[3] = bf2f((u16)(h.y >> 16));
+  return v;
+}
+
+// 4 consecutive channels at element offset `o` of a typed tensor (fp32 rows or bf16 hi[/lo] planes)
+__device__ __forceinline__ f32x4 tload4(const TensorRef& t, long o, int nvalid_c, bool vec_ok) {
+  if (t.fmt == TF_F32) return load4((const float*)t.p + o, nvalid_c, vec_ok);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  const u16* h = (const u16*)t.p + o;
+  const u16* l = t.lo ? (const u16*)t.lo + o : nullptr;
+  if (vec_ok && nvalid_c >= 4) {
+    v = unpack_bf4(*(const uint2*)h);
+    if (l) {
+      const f32x4 w = unpack_bf4(*(const uint2*)l);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += w[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nvalid_c) v[k] = bf2f(h[k]) + (l ? bf2f(l[k]) : 0.f);
+  }
+  return v;
+}
+
+__device__ __forceinline__ void tstore4(const TensorRef& t, long o, f32x4 v, int nvalid_c, bool vec_ok) {
+  if (t.fmt == TF_F32) {
+    float* p = (float*)t.p + o;
+    if (vec_ok && nvalid_c >= 4) {
+      *(f32x4*)p = v;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < nvalid_c) p[k] = v[k];
+    }
+    return;
+  }
+  u16 h[4], l[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h[k] = f2bf(v[k]);
+    l[k] = f2bf(v[k] - bf2f(h[k]));
+  }
+  u16* ph = (u16*)t.p + o;
+  u16* pl = t.lo ? (u16*)t.lo + o : nullptr;
+  if (vec_ok && nvalid_c >= 4) {
+    *(uint2*)ph = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    if (pl) *(uint2*)pl = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < nvalid_c) {
+        ph[k] = h[k];
+        if (pl) pl[k] = l[k];
+      }
+  }
+}
+
 // P::BF == false: img0 = primary (fp32), img2 = secondary.  P::BF: img0 = hi, img1 = lo (may be
 // nullptr: hi only), img2 = secondary.
 template <class P>
@@ -113,7 +177,7 @@ __device__ __forceinline__ void stage_window(const StageSpec& sp, typename P::el
                                              typename P::elem* img2, int RS, int lane) {
   const int nc4 = sp.cwp >> 2;
   const int units = IMG_ROWS * nc4;
-  const bool vec_ok = ((sp.ctot & 3) == 0) && ((sp.coff & 3) == 0) && ((((uintptr_t)sp.src) & 15) == 0);
+  const bool vec_ok = ((sp.ctot & 3) == 0) && ((sp.coff & 3) == 0) && ((((uintptr_t)sp.src.p) & 15) == 0);
   for (int u = lane; u < units; u += WAVE) {
     const int rr = u / nc4;
     const int c = (u - rr * nc4) * 4;
@@ -122,22 +186,22 @@ __device__ __forceinline__ void stage_window(const StageSpec& sp, typename P::el
     f32x4 w = {0.f, 0.f, 0.f, 0.f};
     const int nvc = sp.cw - c;  // valid channels in this unit (may be <= 0)
     if (row >= 0 && row < sp.nvalid && nvc > 0) {
-      const long o = (long)row * sp.ctot + sp.coff + c;
-      v = load4(sp.src + o, nvc, vec_ok);
+      const long o = (sp.row0 + row) * sp.ctot + sp.coff + c;
+      v = tload4(sp.src, o, nvc, vec_ok);
       if (sp.pool) {
         if (row > 0) {
-          const f32x4 a = load4(sp.src + o - sp.ctot, nvc, vec_ok);
+          const f32x4 a = tload4(sp.src, o - sp.ctot, nvc, vec_ok);
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], a[k]);
         }
         if (row + 1 < sp.nvalid) {
-          const f32x4 a = load4(sp.src + o + sp.ctot, nvc, vec_ok);
+          const f32x4 a = tload4(sp.src, o + sp.ctot, nvc, vec_ok);
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], a[k]);
         }
       }
-      if (sp.mask) {
-        const f32x4 m = load4(sp.mask + o, nvc, vec_ok);
+      if (sp.mask.p) {
+        const f32x4 m = tload4(sp.mask, o, nvc, vec_ok);
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = m[k] > 0.f ? v[k] : 0.f;
       }
@@ -160,7 +224,7 @@ __device__ __forceinline__ void stage_window(const StageSpec& sp, typename P::el
 #pragma unroll
         for (int k = 0; k < 4; ++k) w[k] = ((bits >> k) & 1u) ? -v[k] : v[k];
       } else if (sp.second == SEC_MUL) {
-        const f32x4 m = load4(sp.mul + o, nvc, vec_ok);
+        const f32x4 m = tload4(sp.mul, o, nvc, vec_ok);
 #pragma unroll
         for (int k = 0; k < 4; ++k) w[k] = v[k] * m[k];
       }

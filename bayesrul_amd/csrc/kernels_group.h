@@ -80,15 +80,16 @@ __global__ __launch_bounds__(256) void group_fwd_kernel(const GroupArgs A) {
         const bool need = (EM == EM_FLIPOUT) || staged_off != br.in_off || staged_pool != br.pool || staged_c0 != c0;
         if (need) {
           StageSpec sp;
-          sp.src = tin.p + (long)W.in_row0 * tin.ctot;
+          sp.src = tin;
+          sp.row0 = W.in_row0;
           sp.ctot = tin.ctot;
           sp.coff = br.in_off + c0;
           sp.cw = br.cin_real - c0;
           sp.cwp = cwp;
           sp.nvalid = W.nvalid;
           sp.pool = br.pool;
-          sp.mask = nullptr;
-          sp.mul = nullptr;
+          sp.mask = TensorRef{nullptr, nullptr, 0, 0};
+          sp.mul = TensorRef{nullptr, nullptr, 0, 0};
           sp.sign = nullptr;
           sp.sign_stride = 0;
           sp.sign_per_row = G.is_dense;
@@ -172,26 +173,13 @@ __global__ __launch_bounds__(256) void group_fwd_kernel(const GroupArgs A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
           }
-          float* o = tout.p + (long)R * tout.ctot + br.out_off + chb;
-          const bool full = (chb + 4 <= br.cout) && ((tout.ctot & 3) == 0) && ((br.out_off & 3) == 0);
-          if (full) {
-            *(f32x4*)o = v;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (chb + r < br.cout) o[r] = v[r];
-          }
+          const long oo = (long)R * tout.ctot + br.out_off + chb;
+          const bool full = ((tout.ctot & 3) == 0) && ((br.out_off & 3) == 0);
+          tstore4(tout, oo, v, br.cout - chb, full);
           if constexpr (EM == EM_LRT) {
             if (br.q_t >= 0) {
               const TensorRef tq = A.t[br.q_t];
-              float* qo = tq.p + (long)R * tq.ctot + br.out_off + chb;
-              if (full) {
-                *(f32x4*)qo = qv;
-              } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  if (chb + r < br.cout) qo[r] = qv[r];
-              }
+              tstore4(tq, (long)R * tq.ctot + br.out_off + chb, qv, br.cout - chb, full);
             }
           }
         }
@@ -248,15 +236,16 @@ __global__ __launch_bounds__(256) void group_dx_kernel(const GroupArgs A) {
           const TensorRef tg = A.t[br.out_t + T_GRAD];
           const TensorRef ty = A.t[br.out_t];
           StageSpec sp;
-          sp.src = tg.p + (long)W.out_row0 * tg.ctot;
+          sp.src = tg;
+          sp.row0 = W.out_row0;
           sp.ctot = tg.ctot;
           sp.coff = br.out_off;
           sp.cw = br.cout;
           sp.cwp = cwp;
           sp.nvalid = W.nvalid;
           sp.pool = 0;
-          sp.mask = br.relu ? ty.p + (long)W.out_row0 * ty.ctot : nullptr;
-          sp.mul = nullptr;
+          sp.mask = br.relu ? ty : TensorRef{nullptr, nullptr, 0, 0};
+          sp.mul = TensorRef{nullptr, nullptr, 0, 0};
           sp.sign = nullptr;
           sp.sign_stride = 0;
           sp.sign_per_row = G.is_dense;
@@ -265,7 +254,7 @@ __global__ __launch_bounds__(256) void group_dx_kernel(const GroupArgs A) {
           if (EM == EM_LRT) {
             const TensorRef tq = A.t[br.q_t];
             sp.second = SEC_MUL;
-            sp.mul = tq.p + (long)W.out_row0 * tq.ctot;
+            sp.mul = tq;
           }
           if (EM == EM_FLIPOUT) {
             sp.second = SEC_SIGN;
@@ -311,15 +300,15 @@ __global__ __launch_bounds__(256) void group_dx_kernel(const GroupArgs A) {
                   const bool ok = (cimg + 4 <= br.in_off + br.cin_real);
                   f32x4 xv = {0.f, 0.f, 0.f, 0.f};
                   if (ok) {
-                    xv = *(const f32x4*)(tin.p + o);
+                    xv = tload4(tin, o, 4, true);
                     if (br.pool) {
                       if (row > 0) {
-                        const f32x4 a = *(const f32x4*)(tin.p + o - tin.ctot);
+                        const f32x4 a = tload4(tin, o - tin.ctot, 4, true);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xv[r] = fmaxf(xv[r], a[r]);
                       }
                       if (row + 1 < W.nvalid) {
-                        const f32x4 a = *(const f32x4*)(tin.p + o + tin.ctot);
+                        const f32x4 a = tload4(tin, o + tin.ctot, 4, true);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xv[r] = fmaxf(xv[r], a[r]);
                       }
@@ -360,7 +349,7 @@ __global__ __launch_bounds__(256) void group_dx_kernel(const GroupArgs A) {
         for (int mt = 0; mt < 2; ++mt) {
           const int row = mt * 16 + j;
           if (row >= W.nvalid) continue;
-          *(f32x4*)(tdx.p + (long)(W.in_row0 + row) * tdx.ctot + ch) = acc_t[nt][mt];
+          tstore4(tdx, (long)(W.in_row0 + row) * tdx.ctot + ch, acc_t[nt][mt], 4, true);
         }
       }
     }
@@ -434,15 +423,16 @@ __global__ __launch_bounds__(NW * 64) void group_dw_kernel(const GroupArgs A) {
       const bool live = wl < pp;
       if (live) W = decode_win(G, A.cg, s * pp + wl);
       // dZ (+ dZ*q | dZ*s_out)
-      sz.src = live ? tg.p + (long)W.out_row0 * tg.ctot : tg.p;
+      sz.src = tg;
+      sz.row0 = live ? W.out_row0 : 0;
       sz.ctot = tg.ctot;
       sz.coff = br.out_off;
       sz.cw = br.cout;
       sz.cwp = zwp;
       sz.nvalid = live ? W.nvalid : 0;
       sz.pool = 0;
-      sz.mask = (br.relu && live) ? ty.p + (long)W.out_row0 * ty.ctot : nullptr;
-      sz.mul = nullptr;
+      sz.mask = (br.relu && live) ? ty : TensorRef{nullptr, nullptr, 0, 0};
+      sz.mul = TensorRef{nullptr, nullptr, 0, 0};
       sz.sign = nullptr;
       sz.sign_stride = 0;
       sz.sign_per_row = G.is_dense;
@@ -451,7 +441,7 @@ __global__ __launch_bounds__(NW * 64) void group_dw_kernel(const GroupArgs A) {
       if (EM == EM_LRT && live) {
         const TensorRef tq = A.t[br.q_t];
         sz.second = SEC_MUL;
-        sz.mul = tq.p + (long)W.out_row0 * tq.ctot;
+        sz.mul = tq;
       }
       if (EM == EM_FLIPOUT && live) {
         sz.second = SEC_SIGN;
@@ -461,15 +451,16 @@ __global__ __launch_bounds__(NW * 64) void group_dw_kernel(const GroupArgs A) {
       if (DUAL && !live) sz.second = SEC_SQUARE;  // zeros
       stage_window<P>(sz, dz_of(wave), nullptr, dz2_of(wave), RSz, lane);
       // X (+ X^2 | X*s_in)
-      sx.src = live ? tin.p + (long)W.in_row0 * tin.ctot : tin.p;
+      sx.src = tin;
+      sx.row0 = live ? W.in_row0 : 0;
       sx.ctot = tin.ctot;
       sx.coff = br.in_off + c0;
       sx.cw = br.cin_real - c0;
       sx.cwp = (cwp + 15) & ~15;
       sx.nvalid = live ? W.nvalid : 0;
       sx.pool = br.pool;
-      sx.mask = nullptr;
-      sx.mul = nullptr;
+      sx.mask = TensorRef{nullptr, nullptr, 0, 0};
+      sx.mul = TensorRef{nullptr, nullptr, 0, 0};
       sx.sign = nullptr;
       sx.sign_stride = 0;
       sx.sign_per_row = G.is_dense;

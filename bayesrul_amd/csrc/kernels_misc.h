@@ -459,29 +459,42 @@ __global__ void clipped_adam_kernel(const AdamArgs A) {
 // MaxPool1d(3,1,1) backward: dX[r][c] += sum_{r' in {r-1,r,r+1}} dP[r'][c] * [argmax(r') == r]
 // (first maximum wins on ties, as torch's max_pool backward)
 // ------------------------------------------------------------------------------------------
-__global__ void pool_bwd_kernel(const float* X, const float* dP, float* dX, long nwin, int L, int C) {
+__device__ __forceinline__ float tget(const TensorRef& t, long o) {
+  if (t.fmt == TF_F32) return ((const float*)t.p)[o];
+  return bf2f(((const u16*)t.p)[o]) + (t.lo ? bf2f(((const u16*)t.lo)[o]) : 0.f);
+}
+__device__ __forceinline__ void tput(const TensorRef& t, long o, float v) {
+  if (t.fmt == TF_F32) {
+    ((float*)t.p)[o] = v;
+    return;
+  }
+  const u16 h = f2bf(v);
+  ((u16*)t.p)[o] = h;
+  if (t.lo) ((u16*)t.lo)[o] = f2bf(v - bf2f(h));
+}
+
+__global__ void pool_bwd_kernel(const TensorRef X, const TensorRef dP, const TensorRef dX, long nwin, int L, int C) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nwin * L * C) return;
   const int c = (int)(idx % C);
   const long rw = idx / C;
   const int r = (int)(rw % L);
   const long w = rw / L;
-  const float* xw = X + w * L * C + c;
-  const float* dw = dP + w * L * C + c;
+  const long base = w * L * C + c;
   float acc = 0.f;
   for (int rp = max(r - 1, 0); rp <= min(r + 1, L - 1); ++rp) {
     int am = -1;
     float best = 0.f;
     for (int k = max(rp - 1, 0); k <= min(rp + 1, L - 1); ++k) {
-      const float v = xw[(long)k * C];
+      const float v = tget(X, base + (long)k * C);
       if (am < 0 || v > best) {
         best = v;
         am = k;
       }
     }
-    if (am == r) acc += dw[(long)rp * C];
+    if (am == r) acc += tget(dP, base + (long)rp * C);
   }
-  dX[idx] += acc;
+  tput(dX, idx, tget(dX, idx) + acc);
 }
 
 // ------------------------------------------------------------------------------------------

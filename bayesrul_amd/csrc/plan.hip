@@ -47,8 +47,9 @@ enum { TI_ACT1 = 0, TI_MID = 1, TI_ACT2 = 2, TI_H = 3, TI_Z = 4, TI_H2 = 5, TI_H
 struct TensorSpec {
   int ctot = 0;
   int rows_per_example = 0;  // L for conv tensors, 1 for dense
-  long off = -1;             // float offset in workspace (acts); grads / q have their own
-  long goff = -1, qoff = -1;
+  int fmt = TF_F32;          // storage of the activation / its gradient / its LRT q
+  size_t off = 0, off_lo = 0;  // BYTE offsets inside the tensor region: act (hi | f32), act lo plane
+  size_t goff = 0, qoff = 0;   // gradient, q (single plane)
   int alias = -1;            // shares memory with this tensor id
 };
 
@@ -357,28 +358,37 @@ static void layout_workspace(BnnPlan* p) {
   p->o_preds = take((size_t)S * p->d.max_batch * 2 * 4);
   p->o_poolgrad = take((size_t)cap * p->d.win_length * 112 * 4);
   p->o_tens = o;
-  // activations / grads / q
-  long fo = 0;
+  // activations / grads / q.  f32 plans keep fp32 rows; bf16x3 plans keep bf16 planes
+  // (activation = hi + lo planes, gradient and q = one plane) except the net output z.
+  size_t fo = 0;
+  auto takeb = [&](size_t bytes) {
+    size_t r = fo;
+    fo += (bytes + 255) & ~(size_t)255;
+    return r;
+  };
   for (int t = 0; t < 10; ++t) {
     TensorSpec& ts = p->tens[t];
     if (ts.ctot == 0 || ts.alias >= 0) continue;
-    const long n = rupl((long)cap * ts.rows_per_example * ts.ctot, 64);
-    ts.off = fo;
-    fo += n;
-    ts.goff = fo;
-    fo += n;
-    ts.qoff = fo;
-    fo += n;
+    const size_t n = (size_t)cap * ts.rows_per_example * ts.ctot;
+    ts.fmt = (p->d.prec == BNN_PREC_BF16X3 && t != TI_Z) ? TF_BF16 : TF_F32;
+    const size_t eb = ts.fmt == TF_BF16 ? 2 : 4;
+    ts.off = takeb(n * eb);
+    ts.off_lo = ts.fmt == TF_BF16 ? takeb(n * eb) : 0;
+    ts.goff = takeb(n * eb);
+    ts.qoff = takeb(n * eb);
   }
   for (int t = 0; t < 10; ++t) {
     TensorSpec& ts = p->tens[t];
     if (ts.alias >= 0) {
-      ts.off = p->tens[ts.alias].off;
-      ts.goff = p->tens[ts.alias].goff;
-      ts.qoff = p->tens[ts.alias].qoff;
+      const TensorSpec& o = p->tens[ts.alias];
+      ts.fmt = o.fmt;
+      ts.off = o.off;
+      ts.off_lo = o.off_lo;
+      ts.goff = o.goff;
+      ts.qoff = o.qoff;
     }
   }
-  p->ws_bytes = p->o_tens + (size_t)fo * 4;
+  p->ws_bytes = p->o_tens + fo;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -456,11 +466,17 @@ extern "C" int bnn_plan_layer(const BnnPlan* p, int32_t i, const char** name, in
 }
 
 static float* ws_f(const BnnPlan* p, size_t off) { return (float*)((char*)p->bufs.workspace + off); }
-static float* tens_ptr(const BnnPlan* p, int t, int which /*0 act,1 grad,2 q*/) {
+static TensorRef tens_ref(const BnnPlan* p, int t, int which /*0 act,1 grad,2 q*/) {
   const TensorSpec& ts = p->tens[t];
-  const long o = which == 0 ? ts.off : (which == 1 ? ts.goff : ts.qoff);
-  return ws_f(p, p->o_tens) + o;
+  char* base = (char*)p->bufs.workspace + p->o_tens;
+  TensorRef r{};
+  r.ctot = ts.ctot;
+  r.fmt = ts.fmt;
+  r.p = base + (which == 0 ? ts.off : (which == 1 ? ts.goff : ts.qoff));
+  r.lo = (which == 0 && ts.fmt == TF_BF16) ? base + ts.off_lo : nullptr;
+  return r;
 }
+static float* tens_ptr(const BnnPlan* p, int t, int which) { return (float*)tens_ref(p, t, which).p; }
 
 extern "C" int bnn_plan_bind(BnnPlan* p, const BnnBuffers* b) {
   if (!p || !b) return fail(BNN_E_INVALID, "null argument");
@@ -486,6 +502,7 @@ extern "C" int bnn_plan_bind(BnnPlan* p, const BnnBuffers* b) {
 extern "C" int bnn_plan_tensor(const BnnPlan* p, int32_t which, float** ptr, int64_t* rows, int32_t* ctot) {
   if (!p || !p->bound) return fail(BNN_E_UNBOUND, "plan not bound");
   if (which < 0 || which > 7 || p->tens[which].ctot == 0) return fail(BNN_E_INVALID, "tensor %d not part of this net", which);
+  if (p->tens[which].fmt != TF_F32) return fail(BNN_E_INVALID, "tensor %d is stored as bf16 planes (debug access needs an f32 plan)", which);
   if (ptr) *ptr = tens_ptr(p, which, 0);
   if (rows) *rows = (int64_t)p->last_S * p->last_B * p->tens[which].rows_per_example;
   if (ctot) *ctot = p->tens[which].ctot;
@@ -684,12 +701,12 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
   A->nz = c->nz;
   for (int t = 0; t < 10; ++t) {
     if (p->tens[t].ctot == 0) continue;
-    A->t[t] = TensorRef{tens_ptr(p, t, 0), p->tens[t].ctot, 0};
-    A->t[t + T_GRAD] = TensorRef{tens_ptr(p, t, 1), p->tens[t].ctot, 0};
-    A->t[t + T_Q] = TensorRef{tens_ptr(p, t, 2), p->tens[t].ctot, 0};
+    A->t[t] = tens_ref(p, t, 0);
+    A->t[t + T_GRAD] = tens_ref(p, t, 1);
+    A->t[t + T_Q] = tens_ref(p, t, 2);
   }
-  A->t[T_X] = TensorRef{const_cast<float*>(x), p->x_ctot, 0};
-  A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), 112, 0};
+  A->t[T_X] = TensorRef{const_cast<float*>(x), nullptr, p->x_ctot, TF_F32};
+  A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), nullptr, 112, p->d.prec == BNN_PREC_BF16X3 ? TF_BF16 : TF_F32};
   A->layers = (const LayerDesc*)(w + p->o_layers);
   A->gw_a = ws_f(p, p->o_gw_a);
   A->gw_b = ws_f(p, p->o_gw_b);
@@ -900,7 +917,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       const long n = nwin * L * C;
       ProfScope ps_(&p->prof, PK_POOLBWD, gi, c->st);
       pool_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(
-          tens_ptr(p, tin, 0), ws_f(p, p->o_poolgrad), tens_ptr(p, tin, 1), nwin, L, C);
+          A.t[tin], A.t[T_POOLGRAD], A.t[tin + T_GRAD], nwin, L, C);
       HIP_TRY(hipGetLastError());
     }
   }

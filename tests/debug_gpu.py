@@ -44,7 +44,7 @@ def run(net, mode, prec, S=2, B=3, q_boost=20.0):
     print(f"== {net} {mode} {prec}: loss dev {float(res[0]):.9g} oracle {float(loss_o):.9g} | kl {float(res[1]):.9g} / {float(aux['kl']):.9g} | ll {float(res[2]):.9g} / {float(aux['loglik']):.9g}")
     print("   preds relerr", rel_l2(preds, aux["preds"]))
     L = 30
-    if net == "inception":
+    if net == "inception" and prec == "f32":
         t1, tm, t2, th, tz = (eng.tensor(w).double() for w in (N.T_ACT1, N.T_MID, N.T_ACT2, N.T_H, N.T_Z))
         for s in range(S):
             cap, pred = capture(cfg, st, x, noise[s], cfg.mode)
