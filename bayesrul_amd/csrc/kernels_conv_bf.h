@@ -325,3 +325,871 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs 
     }
   }
 }
+
+// ==========================================================================================
+// conv_fwd_bf_kernel : variational forward of a conv group, all branches, bf16 planes.
+//   * the (n-tile, k-step range) JOBS of a wave and their weight fragments (hi, lo, B slot) live
+//     in registers for the whole kernel; windows stream through one shared LDS image set;
+//   * staging = straight 16-byte copies of the bf16 hi/lo planes, register-prefetched TWO windows
+//     ahead; pooled / squared images are derived in LDS;
+//   * Flipout input signs are XOR masks on the B fragments (constant over the rows of a window);
+//   * jobs may split K across waves (block-2 k3/k5 branches have only one n-tile each): partial
+//     accumulators are reduced through LDS by the owning wave.
+// ==========================================================================================
+struct FwdJob {
+  signed char b, nt, ks0, ks1;   // branch (-1: none), n-tile, k-step range [ks0, ks1)
+  signed char grp, owner, member, nmember;  // K-split reduction group (-1: none)
+};
+
+struct ConvFwdPlan {
+  int nsplit, has_pool, n_red_groups, pad_;
+  FwdJob job[CV_WAVES][2];
+};
+
+template <int EM, int KS, int MAXJ>
+__global__ __launch_bounds__(CV_THREADS) void conv_fwd_bf_kernel(const GroupArgs A, const ConvFwdPlan F) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool DUAL = (EM != EM_PLAIN);
+  constexpr bool LRT = (EM == EM_LRT);
+  constexpr int PU = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GroupDesc& G = A.g;
+  const int s = blockIdx.x / F.nsplit, split = blockIdx.x - s * F.nsplit;
+  const int L = G.L, B = A.cg.B;
+  const int cwp = G.in_cin_p, c8n = cwp >> 3;
+  const int RS = img_row_stride(cwp, true);
+  const int pbytes = (IMG_ROWS * RS * 2 + 15) & ~15;  // one plane
+  u16* im_hi = (u16*)smem;                  // direct hi | lo, pooled hi | lo, squares direct | pooled
+  u16* im_lo = (u16*)(smem + pbytes);
+  u16* im_sq = (u16*)(smem + 4 * pbytes);
+  float* red = (float*)(smem + 6 * pbytes);
+  {
+    const int total = (6 * pbytes) >> 2;
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < total; k += CV_THREADS) z[k] = 0u;
+  }
+  const TensorRef tin = A.t[G.in_t];
+  const u16* g_hi = (const u16*)tin.p;
+  const u16* g_lo = (const u16*)tin.lo;
+  const int nu = L * c8n;  // 16-byte units per plane
+
+  // ---- jobs + weights -> registers ----
+  const int i16 = lane & 15, g4 = lane >> 4;
+  bf16x8 w_hi[MAXJ][KS], w_lo[MAXJ][KS], w_b[MAXJ][KS];
+  int boff[MAXJ][KS];       // LDS element offset of the lane's B fragment (mt = 0), incl. image select
+  int c8of[MAXJ][KS];       // channel group (for the sign masks)
+  int j_b[MAXJ], j_nt[MAXJ], j_nks[MAXJ], j_grp[MAXJ], j_owner[MAXJ], j_member[MAXJ], j_nmem[MAXJ];
+  // epilogue data of the job, hoisted out of the window loop (no dependent global loads per window)
+  f32x4 e_ba[MAXJ], e_bb[MAXJ];          // bias (mean | sampled) and LRT bias variance of the lane's 4 channels
+  int e_nv[MAXJ], e_ooff[MAXJ], e_octot[MAXJ], e_relu[MAXJ], e_layer[MAXJ], e_lch[MAXJ], e_cout[MAXJ], e_c4n[MAXJ];
+  u16* e_ohi[MAXJ]; u16* e_olo[MAXJ]; u16* e_q[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; ++j) {
+    const FwdJob J = F.job[wave][j];
+    j_b[j] = J.b;
+    j_nt[j] = J.nt;
+    j_nks[j] = J.b >= 0 ? (J.ks1 - J.ks0) : 0;
+    j_grp[j] = J.grp;
+    j_owner[j] = J.owner;
+    j_member[j] = J.member;
+    j_nmem[j] = J.nmember;
+    e_ba[j] = e_bb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    e_nv[j] = e_ooff[j] = e_octot[j] = e_relu[j] = e_layer[j] = e_lch[j] = e_cout[j] = e_c4n[j] = 0;
+    e_ohi[j] = e_olo[j] = e_q[j] = nullptr;
+    if (J.b >= 0) {
+      const BranchDesc& br = G.br[J.b];
+      const LayerDesc& ly = A.layers[br.layer];
+      const int chb = J.nt * 16 + 4 * g4;
+      e_nv[j] = br.cout - chb;  // <= 0: this lane has no real channel
+      const float* ba = A.ws.bias_a + (long)A.ws.bias_stride_a * s + ly.bias_off + br.n_off + chb;
+      const float* bb = A.ws.bias_b + ly.bias_off + br.n_off + chb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < e_nv[j]) {
+          e_ba[j][r] = ba[r];
+          if constexpr (LRT) e_bb[j][r] = bb[r];
+        }
+      const TensorRef tout = A.t[br.out_t];
+      e_ohi[j] = (u16*)tout.p;
+      e_olo[j] = (u16*)tout.lo;
+      e_q[j] = (u16*)A.t[br.q_t].p;
+      e_octot[j] = tout.ctot;
+      e_ooff[j] = br.out_off + chb;
+      e_relu[j] = br.relu;
+      e_layer[j] = br.layer;
+      e_lch[j] = br.n_off + chb;
+      e_cout[j] = ly.cout;
+      e_c4n[j] = ly.cout_p16 >> 2;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      w_hi[j][ks] = w_lo[j][ks] = w_b[j][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      boff[j][ks] = 0;
+      c8of[j][ks] = 0;
+      if (ks < j_nks[j]) {
+        const BranchDesc& br = G.br[J.b];
+        const LayerDesc& ly = A.layers[br.layer];
+        const int G8 = br.cin_p >> 3;
+        const int gg = (J.ks0 + ks) * 4 + g4;
+        const int tap = gg / G8, c8 = gg - tap * G8;
+        const bool valid = tap < ly.taps;
+        const long wo = (long)(br.n_off + J.nt * 16 + i16) * ly.KP + (long)(J.ks0 + ks) * 32 + g4 * 8;
+        const long sa = A.ws.slot_stride_a * s, sb = A.ws.slot_stride_b * s;
+        w_hi[j][ks] = *(const bf16x8*)((const u16*)A.ws.a_hi + sa + ly.w_off + wo);
+        w_lo[j][ks] = *(const bf16x8*)((const u16*)A.ws.a_lo + sa + ly.w_off + wo);
+        if constexpr (DUAL) w_b[j][ks] = *(const bf16x8*)((const u16*)A.ws.b + sb + ly.w_off + wo);
+        boff[j][ks] = valid ? ((br.pool ? pbytes : 0) + (tap - ly.pad + HALO) * RS + br.in_off + c8 * 8) : 0;
+        c8of[j][ks] = valid ? c8 : 0;
+      }
+    }
+  }
+  // job 1 may reuse job 0's B fragments (same image, channels, taps and k-range)
+  bool same_b = false;
+  if (MAXJ > 1 && j_b[0] >= 0 && j_b[MAXJ - 1] >= 0) {
+    const BranchDesc& b0 = G.br[j_b[0]];
+    const BranchDesc& b1 = G.br[j_b[MAXJ - 1]];
+    const FwdJob J0 = F.job[wave][0], J1 = F.job[wave][MAXJ - 1];
+    same_b = b0.pool == b1.pool && b0.in_off == b1.in_off && b0.cin_p == b1.cin_p &&
+             A.layers[b0.layer].taps == A.layers[b1.layer].taps && J0.ks0 == J1.ks0 && J0.ks1 == J1.ks1;
+  }
+
+  // ---- staging plan: unit U = tid + 512*u over [hi plane | lo plane] ----
+  int st_src[PU], st_dst[PU];
+  bool st_lo[PU], st_ok[PU];
+#pragma unroll
+  for (int u = 0; u < PU; ++u) {
+    const int U = tid + u * CV_THREADS;
+    st_ok[u] = U < 2 * nu;
+    st_lo[u] = U >= nu;
+    const int r = st_lo[u] ? U - nu : U;
+    const int row = r / c8n, c8 = r - row * c8n;
+    st_src[u] = row * tin.ctot + c8 * 8;
+    st_dst[u] = (st_lo[u] ? (pbytes >> 1) : 0) + (row + HALO) * RS + c8 * 8;
+  }
+  uint4 pre0[PU], pre1[PU];
+  uint32_t sg0[MAXJ][4], sg1[MAXJ][4], so0[MAXJ], so1[MAXJ];  // flipout sign words (in: <=128 bits, out: 1 word)
+  auto prefetch = [&](int wl, uint4 (&pre)[PU], uint32_t (&sg)[MAXJ][4], uint32_t (&so)[MAXJ]) {
+    const long row0 = (long)(G.in_bcast ? wl : s * B + wl) * L * tin.ctot;
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      pre[u] = make_uint4(0, 0, 0, 0);
+      if (st_ok[u]) pre[u] = *(const uint4*)((st_lo[u] ? g_lo : g_hi) + row0 + st_src[u]);
+    }
+    if constexpr (EM == EM_FLIPOUT) {
+      const long ex = (long)s * B + wl;
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        sg[j][0] = sg[j][1] = sg[j][2] = sg[j][3] = 0u;
+        so[j] = 0u;
+        if (j_b[j] >= 0) {
+          const BranchDesc& br = G.br[j_b[j]];
+          const LayerDesc& ly = A.layers[br.layer];
+          const uint32_t* pi = A.nz.sign_in + ly.sign_in_off * A.nz.examples + ex * ly.sign_in_words;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (k < ly.sign_in_words) sg[j][k] = pi[k];
+          const int nbit = br.n_off + j_nt[j] * 16;
+          so[j] = A.nz.sign_out[ly.sign_out_off * A.nz.examples + ex * ly.sign_out_words + (nbit >> 5)] >> (nbit & 31);
+        }
+      }
+    }
+  };
+
+  auto step = [&](int wl, uint4 (&pre)[PU], uint32_t (&sg)[MAXJ][4], uint32_t (&so)[MAXJ], int wl_next2) {
+    __syncthreads();  // images of the previous window are no longer read
+#pragma unroll
+    for (int u = 0; u < PU; ++u)
+      if (st_ok[u]) *(uint4*)&im_hi[st_dst[u]] = pre[u];
+    // flipout: keep this window's sign words (the prefetch below reuses the registers)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t sgc[MAXJ][4], so_w[MAXJ];
+    if constexpr (EM == EM_FLIPOUT) {
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        so_w[j] = so[j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sgc[j][k] = sg[j][k];
+      }
+    }
+    __syncthreads();
+    if (wl_next2 >= 0) prefetch(wl_next2, pre, sg, so);  // lands two windows later
+    if (F.has_pool || LRT) {
+      for (int U = tid; U < nu; U += CV_THREADS) {
+        const int row = U / c8n, c8 = U - row * c8n;
+        const int o = (row + HALO) * RS + c8 * 8;
+        const uint4 h0 = *(const uint4*)&im_hi[o], l0 = *(const uint4*)&im_lo[o];
+        const uint32_t hh[4] = {h0.x, h0.y, h0.z, h0.w}, ll[4] = {l0.x, l0.y, l0.z, l0.w};
+        uint32_t ph[4], pl[4], sq[4], psq[4];
+        uint32_t ha[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0}, hb[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0};
+        const bool up = row > 0, dn = row + 1 < L;
+        if (F.has_pool) {
+          if (up) {
+            const uint4 a = *(const uint4*)&im_hi[o - RS], b = *(const uint4*)&im_lo[o - RS];
+            ha[0] = a.x; ha[1] = a.y; ha[2] = a.z; ha[3] = a.w;
+            la[0] = b.x; la[1] = b.y; la[2] = b.z; la[3] = b.w;
+          }
+          if (dn) {
+            const uint4 a = *(const uint4*)&im_hi[o + RS], b = *(const uint4*)&im_lo[o + RS];
+            hb[0] = a.x; hb[1] = a.y; hb[2] = a.z; hb[3] = a.w;
+            lb[0] = b.x; lb[1] = b.y; lb[2] = b.z; lb[3] = b.w;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t oh = 0, ol = 0, os = 0, ops = 0;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int sh = 16 * e;
+            const u16 h = (u16)(hh[k] >> sh), l = (u16)(ll[k] >> sh);
+            u16 bh_ = h, bl_ = l;
+            if (F.has_pool) {
+              float best = bf2f(h) + bf2f(l);
+              if (up) {
+                const u16 h2 = (u16)(ha[k] >> sh), l2 = (u16)(la[k] >> sh);
+                const float v = bf2f(h2) + bf2f(l2);
+                if (v > best) { best = v; bh_ = h2; bl_ = l2; }
+              }
+              if (dn) {
+                const u16 h2 = (u16)(hb[k] >> sh), l2 = (u16)(lb[k] >> sh);
+                const float v = bf2f(h2) + bf2f(l2);
+                if (v > best) { best = v; bh_ = h2; bl_ = l2; }
+              }
+            }
+            oh |= (uint32_t)bh_ << sh;
+            ol |= (uint32_t)bl_ << sh;
+            if constexpr (LRT) {
+              const float x = bf2f(h), xp = bf2f(bh_);
+              os |= (uint32_t)f2bf(x * x) << sh;
+              ops |= (uint32_t)f2bf(xp * xp) << sh;
+            }
+          }
+          ph[k] = oh; pl[k] = ol; sq[k] = os; psq[k] = ops;
+        }
+        if (F.has_pool) {
+          *(uint4*)&im_hi[(pbytes) + o] = make_uint4(ph[0], ph[1], ph[2], ph[3]);        // pooled hi  (plane 2)
+          *(uint4*)&im_hi[(pbytes) + (pbytes >> 1) + o] = make_uint4(pl[0], pl[1], pl[2], pl[3]);  // pooled lo (plane 3)
+        }
+        if constexpr (LRT) {
+          *(uint4*)&im_sq[o] = make_uint4(sq[0], sq[1], sq[2], sq[3]);
+          if (F.has_pool) *(uint4*)&im_sq[(pbytes >> 1) + o] = make_uint4(psq[0], psq[1], psq[2], psq[3]);
+        }
+      }
+      __syncthreads();
+    }
+    // ---------------- MFMA ----------------
+    f32x4 acc_a[MAXJ][2], acc_b[MAXJ][2];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        acc_a[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc_b[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    bf16x8 bh[2], bl[2], b2[2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int j = 0; j < MAXJ; ++j) {
+        if (ks < j_nks[j]) {
+          if (j == 0 || !same_b) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const int o = boff[j][ks] + (mt * 16 + i16) * RS;
+              bh[mt] = *(const bf16x8*)&im_hi[o];
+              bl[mt] = *(const bf16x8*)&im_lo[o];
+              if constexpr (LRT) b2[mt] = *(const bf16x8*)&im_sq[(o >= pbytes ? o - pbytes + (pbytes >> 1) : o)];
+            }
+          }
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            acc_a[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[j][ks], bh[mt], acc_a[j][mt], 0, 0, 0);
+            acc_a[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[j][ks], bl[mt], acc_a[j][mt], 0, 0, 0);
+            acc_a[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[j][ks], bh[mt], acc_a[j][mt], 0, 0, 0);
+            if constexpr (LRT) {
+              acc_b[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[j][ks], b2[mt], acc_b[j][mt], 0, 0, 0);
+            } else if constexpr (EM == EM_FLIPOUT) {
+              // XOR mask of the lane's 8 channels: sign bit of each bf16 (constant over rows)
+              const int c8 = c8of[j][ks];
+              const int wi = c8 >> 2;
+              const uint32_t word = wi == 0 ? sgc[j][0] : (wi == 1 ? sgc[j][1] : (wi == 2 ? sgc[j][2] : sgc[j][3]));
+              const uint32_t byte = (word >> ((c8 & 3) * 8)) & 0xffu;
+              u32x4 fm;
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                fm[k] = (((byte >> (2 * k)) & 1u) << 15) | (((byte >> (2 * k + 1)) & 1u) << 31);
+              const u32x4 xb = __builtin_bit_cast(u32x4, bh[mt]) ^ fm;
+              acc_b[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[j][ks], __builtin_bit_cast(bf16x8, xb),
+                                                                     acc_b[j][mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // ---------------- K-split reduction ----------------
+    if (F.n_red_groups > 0) {
+      if (j_b[0] >= 0 && j_grp[0] >= 0) {
+        float* r = red + (size_t)wave * (2 * 2 * 256);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          *(f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4] = acc_a[0][mt];
+          if constexpr (DUAL) *(f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4] = acc_b[0][mt];
+        }
+      }
+      __syncthreads();
+      if (j_b[0] >= 0 && j_grp[0] >= 0 && j_owner[0]) {
+        // members of a group are consecutive waves starting at the owner
+        for (int m = 1; m < j_nmem[0]; ++m) {
+          const float* r = red + (size_t)(wave + m) * (2 * 2 * 256);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 pa = *(const f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc_a[0][mt][k] += pa[k];
+            if constexpr (DUAL) {
+              const f32x4 pb = *(const f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) acc_b[0][mt][k] += pb[k];
+            }
+          }
+        }
+      }
+    }
+    // ---------------- epilogue ----------------
+    const int w = s * B + wl;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      if (j_b[j] < 0 || e_nv[j] <= 0) continue;
+      if (j_grp[j] >= 0 && !j_owner[j]) continue;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 16 + i16;
+        if (row >= L) continue;
+        const int R = w * L + row;
+        f32x4 v = acc_a[j][mt];
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (LRT) {
+          f32x4 eps;
+          if (A.nz.use_philox_lrt) {
+            const long Rg = global_row(A.cg, L, R);
+            const uint64_t idx = (uint64_t)Rg * (uint64_t)e_c4n[j] + (uint64_t)(e_lch[j] >> 2);
+            eps = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)e_layer[j] << 8), A.nz.step,
+                                 A.nz.seed);
+          } else {
+            const float* e = A.nz.lrt_eps[e_layer[j]] + (long)R * e_cout[j] + e_lch[j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) eps[r] = (r < e_nv[j]) ? e[r] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float loc = v[r] + e_ba[j][r];
+            float var = acc_b[j][mt][r] + e_bb[j][r];
+            if (var < 0.f) var = 1e-6f;
+            const float sd = sqrtf(var);
+            v[r] = loc + sd * eps[r];
+            qv[r] = sd > 0.f ? eps[r] / (2.f * sd) : 0.f;
+          }
+        } else if constexpr (EM == EM_FLIPOUT) {
+          const uint32_t bits = so_w[j] >> (4 * g4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pb = acc_b[j][mt][r];
+            v[r] = v[r] + e_ba[j][r] + (((bits >> r) & 1u) ? -pb : pb);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += e_ba[j][r];
+        }
+        if (e_relu[j]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        const long oo = (long)R * e_octot[j] + e_ooff[j];
+        u16 h[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[r] = f2bf(v[r]);
+          l[r] = f2bf(v[r] - bf2f(h[r]));
+        }
+        if (e_nv[j] >= 4) {
+          *(uint2*)(e_ohi[j] + oo) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+          *(uint2*)(e_olo[j] + oo) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+          if constexpr (LRT) *(uint2*)(e_q[j] + oo) = pack_bf4(qv);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < e_nv[j]) {
+              e_ohi[j][oo + r] = h[r];
+              e_olo[j][oo + r] = l[r];
+              if constexpr (LRT) e_q[j][oo + r] = f2bf(qv[r]);
+            }
+        }
+      }
+    }
+  };
+
+  const int pp = B;
+  int wl = split;
+  if (wl < pp) prefetch(wl, pre0, sg0, so0);
+  if (wl + F.nsplit < pp) prefetch(wl + F.nsplit, pre1, sg1, so1);
+  for (; wl < pp; wl += 2 * F.nsplit) {
+    const int n2 = wl + 2 * F.nsplit, n3 = wl + 3 * F.nsplit;
+    step(wl, pre0, sg0, so0, n2 < pp ? n2 : -1);
+    if (wl + F.nsplit < pp) step(wl + F.nsplit, pre1, sg1, so1, n3 < pp ? n3 : -1);
+  }
+}
+
+
+// x [rows][F] fp32 -> bf16 hi/lo planes [rows][CP] (zero padded channels); once per call
+__global__ void x_planes_kernel(const float* x, u16* hi, u16* lo, long rows, int F, int CP) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * CP) return;
+  const long r = idx / CP;
+  const int c = (int)(idx - r * CP);
+  const float v = c < F ? x[r * F + c] : 0.f;
+  const u16 h = f2bf(v);
+  hi[idx] = h;
+  lo[idx] = f2bf(v - bf2f(h));
+}
+
+// ==========================================================================================
+// conv_fwd_dma_kernel : role-specialised forward of a conv group (bf16 planes).
+//   16 waves: waves [0, FW_NC) compute (one (n-tile, k-range) job each, weight fragments in
+//   registers), waves [FW_NC, 16) are LOADERS that move the next windows' hi/lo planes
+//   global -> LDS with LDS-DMA (global_load_lds_dwordx4), two windows ahead, and never touch a
+//   register or a store: their vmcnt counts nothing but their own DMAs, so the counted wait
+//   is exact.  Compute waves never wait on memory inside the window loop (their epilogue
+//   stores are fire-and-forget).  LDS images are dense copies of the global rows; bank
+//   conflicts are removed by an XOR swizzle applied to the per-lane SOURCE address of the DMA
+//   and to every read (chunk position p of image row r holds channel chunk p ^ (r & mask)).
+// ==========================================================================================
+enum { FW_WAVES = 16, FW_THREADS = 1024, FW_NC = 12, FW_NL = 4, FW_KS = 4, FW_SLOTS = 3 };
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+// LDS-DMA issued through inline asm so that hipcc does not model it: no compiler-inserted
+// vmcnt(0) before later LDS reads / barriers; completion is waited for with explicit counted
+// s_waitcnt vmcnt(N) by the issuing (loader) wave.  M0 carries the wave-uniform LDS byte address
+// and is restored (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_char_t*)p; }
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+// workgroup barrier that only waits for this wave's LDS traffic (never for VMEM)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+struct ConvFwd2Plan {
+  int nsplit, has_pool, n_red_groups, pad_;
+  FwdJob job[FW_NC];
+};
+
+template <int EM>
+__global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArgs A, const ConvFwd2Plan F) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool DUAL = (EM != EM_PLAIN);
+  constexpr bool LRT = (EM == EM_LRT);
+  constexpr int KS = FW_KS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GroupDesc& G = A.g;
+  const int s = blockIdx.x / F.nsplit, split = blockIdx.x - s * F.nsplit;
+  const int L = G.L, B = A.cg.B;
+  const int cwp = G.in_cin_p, c8n = cwp >> 3;
+  const int swm = (c8n - 1) & 15;           // swizzle mask (c8n is a power of two: 4 or 16)
+  const int RS = cwp;                       // dense rows
+  const int pbytes = IMG_ROWS * RS * 2;     // one plane incl. halo rows (multiple of 16)
+  // LDS: raw[FW_SLOTS][hi|lo] | derived: pooled hi | pooled lo | sq | pooled sq | sign words | red
+  u16* raw = (u16*)smem;
+  u16* der = (u16*)(smem + FW_SLOTS * 2 * pbytes);
+  uint32_t* sgn = (uint32_t*)(smem + (FW_SLOTS * 2 + 4) * pbytes);   // [FW_SLOTS][64]
+  float* red = (float*)(smem + (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4);
+  {
+    const int total = ((FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4) >> 2;
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < total; k += FW_THREADS) z[k] = 0u;
+  }
+  const TensorRef tin = A.t[G.in_t];
+  const int nchunk = L * c8n;                       // 16-byte chunks per plane per window
+  const int ninst = (nchunk + 63) >> 6;             // DMA instructions per plane
+  const bool is_loader = wave >= FW_NC;
+  const int lw = wave - FW_NC;
+  const int pp = B;
+  const int nwin = (pp - split + F.nsplit - 1) / F.nsplit;   // windows of this workgroup
+  auto win_of = [&](int k) { return split + k * F.nsplit; };
+
+  // =========================== loader state ===========================
+  // DMA instructions of a window: 2 planes x ninst, dealt round-robin to the 4 loader waves;
+  // addresses are recomputed per issue (no per-thread arrays: they would land in scratch)
+  const int my_ninst = is_loader ? max(0, (2 * ninst - lw + FW_NL - 1) / FW_NL) : 0;
+  // flipout sign words of a window: [branch][8] = 4 words sign_in + 2 words sign_out, by loader 0
+  const uint32_t* sg_src = nullptr;
+  long sg_stride = 0;
+  bool sg_ok = false;
+  if (EM == EM_FLIPOUT && is_loader && lw == 0 && lane < 8 * G.n_branch) {
+    const int b = lane >> 3, k = lane & 7;
+    const BranchDesc& br = G.br[b];
+    const LayerDesc& ly = A.layers[br.layer];
+    if (k < 4 && k < ly.sign_in_words) {
+      sg_src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + k;
+      sg_stride = ly.sign_in_words;
+      sg_ok = true;
+    } else if (k >= 4 && k - 4 < ly.sign_out_words && k < 6) {
+      sg_src = A.nz.sign_out + ly.sign_out_off * A.nz.examples + (k - 4);
+      sg_stride = ly.sign_out_words;
+      sg_ok = true;
+    }
+  }
+  auto issue = [&](int k) {   // DMA window k of this workgroup into slot k % FW_SLOTS
+    const int wl = win_of(k);
+    const long row0 = (long)(G.in_bcast ? wl : s * B + wl) * L * tin.ctot;
+    char* slot = smem + (k % FW_SLOTS) * 2 * pbytes;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+#define BNN_DMA_ONE(I)                                                                              \
+    {                                                                                               \
+      const int inst = lw + (I) * FW_NL;                                                            \
+      if (inst < 2 * ninst) {                                                                       \
+        const int plane = inst >= ninst ? 1 : 0;                                                    \
+        const int q0 = (inst - plane * ninst) * 64;                                                 \
+        const int q = q0 + lane_o;                                                                  \
+        const int row = q / c8n, pz = q - row * c8n;                                                \
+        const int c8 = pz ^ ((row + HALO) & swm);                                                   \
+        const u16* base = (const u16*)(plane ? tin.lo : tin.p) + row0 + (long)row * tin.ctot + c8 * 8; \
+        char* dst = slot + plane * pbytes + (HALO * RS * 2) + q0 * 16;                              \
+        if (q < nchunk) dma16(base, __builtin_amdgcn_readfirstlane(lds_addr(dst)));               \
+      }                                                                                             \
+    }
+    BNN_DMA_ONE(0)
+    BNN_DMA_ONE(1)
+    BNN_DMA_ONE(2)
+    BNN_DMA_ONE(3)
+#undef BNN_DMA_ONE
+    if (EM == EM_FLIPOUT && lw == 0) {
+      if (sg_ok) dma4(sg_src + ((long)s * B + wl) * sg_stride, __builtin_amdgcn_readfirstlane(lds_addr(sgn + (k % FW_SLOTS) * 64)));
+    }
+  };
+
+  // =========================== compute state ===========================
+  const int i16 = lane & 15, g4 = lane >> 4;
+  bf16x8 w_hi[KS], w_lo[KS], w_b[KS];
+  int k_pk[KS];   // packed: image row base (tap - pad + HALO) | global channel chunk << 8 | chunk inside the layer << 16
+  FwdJob J = FwdJob{-1, 0, 0, 0, -1, 0, 0, 0};
+  int j_nks = 0, j_pool = 0;
+  f32x4 e_ba = {0.f, 0.f, 0.f, 0.f}, e_bb = {0.f, 0.f, 0.f, 0.f};
+  int e_nv = 0, e_ooff = 0, e_octot = 0, e_relu = 0, e_layer = 0, e_lch = 0, e_cout = 0, e_c4n = 0, e_sob = 0;
+  u16 *e_ohi = nullptr, *e_olo = nullptr, *e_q = nullptr;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    w_hi[ks] = w_lo[ks] = w_b[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    k_pk[ks] = HALO;
+  }
+  if (!is_loader) {
+    J = F.job[wave];
+    if (J.b >= 0) {
+      const BranchDesc& br = G.br[J.b];
+      const LayerDesc& ly = A.layers[br.layer];
+      j_nks = J.ks1 - J.ks0;
+      j_pool = br.pool;
+      const int G8 = br.cin_p >> 3;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks < j_nks) {
+          const int gg = (J.ks0 + ks) * 4 + g4;
+          const int tap = gg / G8, c8 = gg - tap * G8;
+          const bool valid = tap < ly.taps;
+          const long wo = (long)(br.n_off + J.nt * 16 + i16) * ly.KP + (long)(J.ks0 + ks) * 32 + g4 * 8;
+          const long sa = A.ws.slot_stride_a * s, sb = A.ws.slot_stride_b * s;
+          w_hi[ks] = *(const bf16x8*)((const u16*)A.ws.a_hi + sa + ly.w_off + wo);
+          w_lo[ks] = *(const bf16x8*)((const u16*)A.ws.a_lo + sa + ly.w_off + wo);
+          if constexpr (DUAL) w_b[ks] = *(const bf16x8*)((const u16*)A.ws.b + sb + ly.w_off + wo);
+          k_pk[ks] = valid ? ((tap - ly.pad + HALO) | (((br.in_off >> 3) + c8) << 8) | (c8 << 16)) : HALO;
+        }
+      }
+      const int chb = J.nt * 16 + 4 * g4;
+      e_nv = br.cout - chb;
+      const float* ba = A.ws.bias_a + (long)A.ws.bias_stride_a * s + ly.bias_off + br.n_off + chb;
+      const float* bb = A.ws.bias_b + ly.bias_off + br.n_off + chb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < e_nv) {
+          e_ba[r] = ba[r];
+          if constexpr (LRT) e_bb[r] = bb[r];
+        }
+      const TensorRef tout = A.t[br.out_t];
+      e_ohi = (u16*)tout.p;
+      e_olo = (u16*)tout.lo;
+      e_q = (u16*)A.t[br.q_t].p;
+      e_octot = tout.ctot;
+      e_ooff = br.out_off + chb;
+      e_relu = br.relu;
+      e_layer = br.layer;
+      e_lch = br.n_off + chb;
+      e_cout = ly.cout;
+      e_c4n = ly.cout_p16 >> 2;
+      e_sob = br.n_off + J.nt * 16;   // first sign_out bit of this n-tile
+    }
+  }
+
+  // =========================== prologue ===========================
+  __syncthreads();  // zero fill visible
+  if (is_loader) {
+    if (nwin > 0) issue(0);
+    if (nwin > 1) issue(1);
+  }
+
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  for (int k = 0; k < nwin; ++k) {
+    const int slot = k % FW_SLOTS;
+    u16* r_hi = raw + slot * pbytes;             // 2 planes per slot: elements = 2*pbytes/2
+    u16* r_lo = r_hi + (pbytes >> 1);
+    // ---- window k landed? (loaders: all but the DMAs of window k+1 are complete) ----
+    if (is_loader) {
+      const bool more = (k + 1 < nwin);
+      // my_ninst (+1 sign DMA for loader 0) instructions per window may stay in flight
+      if (!more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (EM == EM_FLIPOUT && lw == 0) {
+        if (my_ninst == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (my_ninst == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (my_ninst == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (my_ninst == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      } else {
+        if (my_ninst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (my_ninst == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (my_ninst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (my_ninst == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    lds_barrier();                                // B1: raw planes of window k visible; compute(k-1) finished
+    // ---- derived planes (all 16 waves) ----
+    if ((F.has_pool || LRT) && !(A.pool_sel & 2)) {
+      for (int U = tid; U < nchunk; U += FW_THREADS) {
+        const int row = U / c8n, p = U - row * c8n;
+        const int ri = row + HALO;
+        const int c8 = p ^ (ri & swm);
+        const int o = ri * RS + p * 8;
+        const uint4 h0 = *(const uint4*)&r_hi[o], l0 = *(const uint4*)&r_lo[o];
+        const uint32_t hh[4] = {h0.x, h0.y, h0.z, h0.w}, ll[4] = {l0.x, l0.y, l0.z, l0.w};
+        uint32_t ha[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0}, hb[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0};
+        const bool up = row > 0, dn = row + 1 < L;
+        if (F.has_pool) {
+          if (up) {
+            const int o2 = (ri - 1) * RS + ((c8 ^ ((ri - 1) & swm)) * 8);
+            const uint4 a = *(const uint4*)&r_hi[o2], b = *(const uint4*)&r_lo[o2];
+            ha[0] = a.x; ha[1] = a.y; ha[2] = a.z; ha[3] = a.w;
+            la[0] = b.x; la[1] = b.y; la[2] = b.z; la[3] = b.w;
+          }
+          if (dn) {
+            const int o2 = (ri + 1) * RS + ((c8 ^ ((ri + 1) & swm)) * 8);
+            const uint4 a = *(const uint4*)&r_hi[o2], b = *(const uint4*)&r_lo[o2];
+            hb[0] = a.x; hb[1] = a.y; hb[2] = a.z; hb[3] = a.w;
+            lb[0] = b.x; lb[1] = b.y; lb[2] = b.z; lb[3] = b.w;
+          }
+        }
+        uint32_t ph[4], pl[4], sq[4], psq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t oh = 0, ol = 0, os = 0, ops = 0;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int sh = 16 * e;
+            const u16 h = (u16)(hh[q] >> sh), l = (u16)(ll[q] >> sh);
+            u16 bh_ = h, bl_ = l;
+            if (F.has_pool) {
+              float best = bf2f(h) + bf2f(l);
+              if (up) {
+                const u16 h2 = (u16)(ha[q] >> sh), l2 = (u16)(la[q] >> sh);
+                const float v = bf2f(h2) + bf2f(l2);
+                if (v > best) { best = v; bh_ = h2; bl_ = l2; }
+              }
+              if (dn) {
+                const u16 h2 = (u16)(hb[q] >> sh), l2 = (u16)(lb[q] >> sh);
+                const float v = bf2f(h2) + bf2f(l2);
+                if (v > best) { best = v; bh_ = h2; bl_ = l2; }
+              }
+            }
+            oh |= (uint32_t)bh_ << sh;
+            ol |= (uint32_t)bl_ << sh;
+            if constexpr (LRT) {
+              const float x = bf2f(h), xp = bf2f(bh_);
+              os |= (uint32_t)f2bf(x * x) << sh;
+              ops |= (uint32_t)f2bf(xp * xp) << sh;
+            }
+          }
+          ph[q] = oh; pl[q] = ol; sq[q] = os; psq[q] = ops;
+        }
+        if (F.has_pool) {
+          *(uint4*)&der[o] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+          *(uint4*)&der[(pbytes >> 1) + o] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+        if constexpr (LRT) {
+          *(uint4*)&der[pbytes + o] = make_uint4(sq[0], sq[1], sq[2], sq[3]);
+          if (F.has_pool) *(uint4*)&der[pbytes + (pbytes >> 1) + o] = make_uint4(psq[0], psq[1], psq[2], psq[3]);
+        }
+      }
+      lds_barrier();                              // B2: derived planes visible
+    }
+    if (is_loader) {
+      if (k + 2 < nwin) issue(k + 2);             // slot (k+2)%3 == (k-1)%3: free since B1
+    }
+    // ---------------- MFMA (compute waves) ----------------
+    f32x4 acc_a[2], acc_b[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      acc_a[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc_b[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    uint32_t so_bits = 0;
+    if (!is_loader && J.b >= 0 && !(A.pool_sel & 4)) {
+      const u16* x_hi = j_pool ? der : r_hi;
+      const u16* x_lo = j_pool ? der + (pbytes >> 1) : r_lo;
+      const u16* x_sq = der + pbytes + (j_pool ? (pbytes >> 1) : 0);
+      const uint32_t* sg = sgn + slot * 64 + J.b * 8;
+      if constexpr (EM == EM_FLIPOUT) so_bits = sg[4 + (e_sob >> 5)] >> (e_sob & 31);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks < j_nks) {
+          u32x4 fm = {0u, 0u, 0u, 0u};
+          if constexpr (EM == EM_FLIPOUT) {
+            const int c8 = (k_pk[ks] >> 16) & 0xff;
+            const uint32_t byte = (sg[c8 >> 2] >> ((c8 & 3) * 8)) & 0xffu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              fm[q] = (((byte >> (2 * q)) & 1u) << 15) | (((byte >> (2 * q + 1)) & 1u) << 31);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const int rr = (k_pk[ks] & 0xff) + mt * 16 + i16;
+            const int o = rr * RS + ((((k_pk[ks] >> 8) & 0xff) ^ (rr & swm)) * 8);
+            const bf16x8 bh = *(const bf16x8*)&x_hi[o];
+            const bf16x8 bl = *(const bf16x8*)&x_lo[o];
+            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bh, acc_a[mt], 0, 0, 0);
+            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bl, acc_a[mt], 0, 0, 0);
+            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[ks], bh, acc_a[mt], 0, 0, 0);
+            if constexpr (LRT) {
+              const bf16x8 b2 = *(const bf16x8*)&x_sq[o];
+              acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], b2, acc_b[mt], 0, 0, 0);
+            } else if constexpr (EM == EM_FLIPOUT) {
+              const u32x4 xb = __builtin_bit_cast(u32x4, bh) ^ fm;
+              acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], __builtin_bit_cast(bf16x8, xb), acc_b[mt], 0,
+                                                                 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // ---------------- K-split reduction ----------------
+    if (F.n_red_groups > 0) {
+      if (!is_loader && J.b >= 0 && J.grp >= 0 && !J.owner) {
+        float* r = red + (size_t)wave * (2 * 2 * 256);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          *(f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4] = acc_a[mt];
+          if constexpr (DUAL) *(f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4] = acc_b[mt];
+        }
+      }
+      lds_barrier();
+      if (!is_loader && J.b >= 0 && J.grp >= 0 && J.owner) {
+        for (int m = 1; m < J.nmember; ++m) {
+          const float* r = red + (size_t)(wave + m) * (2 * 2 * 256);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 pa = *(const f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc_a[mt][q] += pa[q];
+            if constexpr (DUAL) {
+              const f32x4 pb = *(const f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc_b[mt][q] += pb[q];
+            }
+          }
+        }
+      }
+    }
+    // ---------------- epilogue ----------------
+    if (!is_loader && J.b >= 0 && e_nv > 0 && (J.grp < 0 || J.owner) && !(A.pool_sel & 1)) {
+      const int w = s * B + win_of(k);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 16 + i16;
+        if (row >= L) continue;
+        const int R = w * L + row;
+        f32x4 v = acc_a[mt];
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (LRT) {
+          f32x4 eps;
+          if (A.nz.use_philox_lrt) {
+            const long Rg = global_row(A.cg, L, R);
+            const uint64_t idx = (uint64_t)Rg * (uint64_t)e_c4n + (uint64_t)(e_lch >> 2);
+            eps = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)e_layer << 8), A.nz.step,
+                                 A.nz.seed);
+          } else {
+            const float* e = A.nz.lrt_eps[e_layer] + (long)R * e_cout + e_lch;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) eps[r] = (r < e_nv) ? e[r] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float loc = v[r] + e_ba[r];
+            float var = acc_b[mt][r] + e_bb[r];
+            if (var < 0.f) var = 1e-6f;
+            const float sd = sqrtf(var);
+            v[r] = loc + sd * eps[r];
+            qv[r] = sd > 0.f ? eps[r] / (2.f * sd) : 0.f;
+          }
+        } else if constexpr (EM == EM_FLIPOUT) {
+          const uint32_t bits = so_bits >> (4 * g4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pb = acc_b[mt][r];
+            v[r] = v[r] + e_ba[r] + (((bits >> r) & 1u) ? -pb : pb);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += e_ba[r];
+        }
+        if (e_relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        const long oo = (long)R * e_octot + e_ooff;
+        u16 h[4], l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[r] = f2bf(v[r]);
+          l[r] = f2bf(v[r] - bf2f(h[r]));
+        }
+        if (e_nv >= 4) {
+          *(uint2*)(e_ohi + oo) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+          *(uint2*)(e_olo + oo) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+          if constexpr (LRT) *(uint2*)(e_q + oo) = pack_bf4(qv);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < e_nv) {
+              e_ohi[oo + r] = h[r];
+              e_olo[oo + r] = l[r];
+              if constexpr (LRT) e_q[oo + r] = f2bf(qv[r]);
+            }
+        }
+      }
+    }
+  }
+}

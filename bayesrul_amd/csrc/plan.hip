@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -105,7 +106,7 @@ struct BnnPlan {
   // workspace layout (byte offsets)
   size_t ws_bytes = 0;
   size_t o_layers, o_a_hi, o_a_lo, o_b, o_at, o_bt, o_bias_a, o_bias_b, o_gw_a, o_gw_b, o_gb_a, o_gb_b, o_eps, o_radr,
-      o_norms, o_sign_in, o_sign_out, o_acc, o_scal, o_preds, o_poolgrad, o_tens;
+      o_norms, o_sign_in, o_sign_out, o_acc, o_scal, o_preds, o_poolgrad, o_xplanes, o_tens;
   size_t elem = 4;
   bool bound = false;
   BnnBuffers bufs{};
@@ -123,16 +124,16 @@ struct LSpec {
 };
 
 static const LSpec kInception[] = {
-    {"layers.0.conv1.0", 1, 27, 18, 1, 24, CM_IDENT, 0, 0},
-    {"layers.0.conv3.0", 1, 27, 18, 3, 24, CM_IDENT, 0, 0},
-    {"layers.0.conv5.0", 1, 27, 18, 5, 24, CM_IDENT, 0, 0},
-    {"layers.0.convpool.1", 1, 27, 18, 3, 24, CM_IDENT, 0, 0},
-    {"layers.1.branch1.0", 1, 16, 108, 1, 112, CM_BLOCK, 27, 28},
-    {"layers.1.branch2.0", 1, 64, 108, 1, 112, CM_BLOCK, 27, 28},
+    {"layers.0.conv1.0", 1, 27, 18, 1, 32, CM_IDENT, 0, 0},
+    {"layers.0.conv3.0", 1, 27, 18, 3, 32, CM_IDENT, 0, 0},
+    {"layers.0.conv5.0", 1, 27, 18, 5, 32, CM_IDENT, 0, 0},
+    {"layers.0.convpool.1", 1, 27, 18, 3, 32, CM_IDENT, 0, 0},
+    {"layers.1.branch1.0", 1, 16, 108, 1, 128, CM_BLOCK, 27, 32},
+    {"layers.1.branch2.0", 1, 64, 108, 1, 128, CM_BLOCK, 27, 32},
     {"layers.1.branch2.2", 1, 16, 64, 3, 64, CM_IDENT, 0, 0},
-    {"layers.1.branch3.0", 1, 64, 108, 1, 112, CM_BLOCK, 27, 28},
+    {"layers.1.branch3.0", 1, 64, 108, 1, 128, CM_BLOCK, 27, 32},
     {"layers.1.branch3.2", 1, 16, 64, 5, 64, CM_IDENT, 0, 0},
-    {"layers.1.branch4.1", 1, 32, 108, 1, 112, CM_BLOCK, 27, 28},
+    {"layers.1.branch4.1", 1, 32, 108, 1, 128, CM_BLOCK, 27, 32},
     {"layers.3", 0, 64, 2400, 1, 2400, CM_FLATTEN, 80, 30},
     {"last", 0, 2, 64, 1, 64, CM_IDENT, 0, 0},
 };
@@ -253,7 +254,7 @@ static int build_tables(BnnPlan* p) {
   };
   p->n_groups = 0;
   if (inc) {
-    T(TI_ACT1, 112, L);
+    T(TI_ACT1, 128, L);
     T(TI_MID, 128, L);
     T(TI_ACT2, 80, L);
     T(TI_ACT2F, 80 * L, 1, TI_ACT2);
@@ -263,19 +264,19 @@ static int build_tables(BnnPlan* p) {
     GroupDesc g{};
     // block 1 (nets/inception.py:10-61)
     g = GroupDesc{};
-    g.n_branch = 4; g.is_dense = 0; g.in_t = T_X; g.in_bcast = 1; g.L = L; g.in_cin_p = 24;
-    g.br[0] = mk_branch(0, 0, 27, 0, 24, 18, 0, 1, TI_ACT1, 0, -1);
-    g.br[1] = mk_branch(1, 0, 27, 0, 24, 18, 0, 1, TI_ACT1, 28, -1);
-    g.br[2] = mk_branch(2, 0, 27, 0, 24, 18, 0, 1, TI_ACT1, 56, -1);
-    g.br[3] = mk_branch(3, 0, 27, 0, 24, 18, 1, 1, TI_ACT1, 84, -1);
+    g.n_branch = 4; g.is_dense = 0; g.in_t = T_X; g.in_bcast = 1; g.L = L; g.in_cin_p = 32;
+    g.br[0] = mk_branch(0, 0, 27, 0, 32, 18, 0, 1, TI_ACT1, 0, -1);
+    g.br[1] = mk_branch(1, 0, 27, 0, 32, 18, 0, 1, TI_ACT1, 32, -1);
+    g.br[2] = mk_branch(2, 0, 27, 0, 32, 18, 0, 1, TI_ACT1, 64, -1);
+    g.br[3] = mk_branch(3, 0, 27, 0, 32, 18, 1, 1, TI_ACT1, 96, -1);
     p->groups[p->n_groups++] = g;
     // block 2, 1x1 level (nets/inception.py:71-132)
     g = GroupDesc{};
-    g.n_branch = 4; g.is_dense = 0; g.in_t = TI_ACT1; g.in_bcast = 0; g.L = L; g.in_cin_p = 112;
-    g.br[0] = mk_branch(4, 0, 16, 0, 112, 112, 0, 1, TI_ACT2, 0, TI_ACT1 + T_GRAD);
-    g.br[1] = mk_branch(5, 0, 64, 0, 112, 112, 0, 1, TI_MID, 0, TI_ACT1 + T_GRAD);
-    g.br[2] = mk_branch(7, 0, 64, 0, 112, 112, 0, 1, TI_MID, 64, TI_ACT1 + T_GRAD);
-    g.br[3] = mk_branch(9, 0, 32, 0, 112, 112, 1, 1, TI_ACT2, 48, T_POOLGRAD);
+    g.n_branch = 4; g.is_dense = 0; g.in_t = TI_ACT1; g.in_bcast = 0; g.L = L; g.in_cin_p = 128;
+    g.br[0] = mk_branch(4, 0, 16, 0, 128, 128, 0, 1, TI_ACT2, 0, TI_ACT1 + T_GRAD);
+    g.br[1] = mk_branch(5, 0, 64, 0, 128, 128, 0, 1, TI_MID, 0, TI_ACT1 + T_GRAD);
+    g.br[2] = mk_branch(7, 0, 64, 0, 128, 128, 0, 1, TI_MID, 64, TI_ACT1 + T_GRAD);
+    g.br[3] = mk_branch(9, 0, 32, 0, 128, 128, 1, 1, TI_ACT2, 48, T_POOLGRAD);
     p->groups[p->n_groups++] = g;
     // block 2, k3 / k5 level
     g = GroupDesc{};
@@ -356,7 +357,8 @@ static void layout_workspace(BnnPlan* p) {
   p->o_acc = take(sizeof(double) * 2 * (S + 1));
   p->o_scal = take(64);
   p->o_preds = take((size_t)S * p->d.max_batch * 2 * 4);
-  p->o_poolgrad = take((size_t)cap * p->d.win_length * 112 * 4);
+  p->o_poolgrad = take((size_t)cap * p->d.win_length * 128 * 4);
+  p->o_xplanes = take((size_t)2 * p->d.max_batch * p->d.win_length * 32 * 2);
   p->o_tens = o;
   // activations / grads / q.  f32 plans keep fp32 rows; bf16x3 plans keep bf16 planes
   // (activation = hi + lo planes, gradient and q = one plane) except the net output z.
@@ -706,7 +708,12 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
     A->t[t + T_Q] = tens_ref(p, t, 2);
   }
   A->t[T_X] = TensorRef{const_cast<float*>(x), nullptr, p->x_ctot, TF_F32};
-  A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), nullptr, 112, p->d.prec == BNN_PREC_BF16X3 ? TF_BF16 : TF_F32};
+  if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
+    // the conv kernels read the windows as bf16 hi/lo planes [B*L][32] (built by x_planes_kernel)
+    char* xp = (char*)p->bufs.workspace + p->o_xplanes;
+    A->t[T_X] = TensorRef{xp, xp + (size_t)p->d.max_batch * p->d.win_length * 32 * 2, 32, TF_BF16};
+  }
+  A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), nullptr, 128, p->d.prec == BNN_PREC_BF16X3 ? TF_BF16 : TF_F32};
   A->layers = (const LayerDesc*)(w + p->o_layers);
   A->gw_a = ws_f(p, p->o_gw_a);
   A->gw_b = ws_f(p, p->o_gw_b);
@@ -790,6 +797,197 @@ static int launch_dw(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int 
 }
 
 // ---- round-1 optimised bf16 conv-group kernels (kernels_conv_bf.h) ----
+static int build_conv_fwd_plan(const GroupArgs& A, const LayerDesc* layers, ConvFwdPlan* F, int* ks_needed) {
+  *F = ConvFwdPlan{};
+  for (int w = 0; w < CV_WAVES; ++w)
+    for (int j = 0; j < 2; ++j) F->job[w][j].b = -1;
+  struct Tile { int b, nt, ks; };
+  std::vector<Tile> tiles;
+  int total_ks = 0;
+  for (int b = 0; b < A.g.n_branch; ++b) {
+    const BranchDesc& br = A.g.br[b];
+    const LayerDesc& ly = layers[br.layer];
+    if (br.pool) F->has_pool = 1;
+    const int ks = (ly.taps * (br.cin_p / 8) + 3) / 4;
+    for (int n = 0; n < br.ntiles; ++n) {
+      tiles.push_back({b, n, ks});
+      total_ks += ks;
+    }
+  }
+  int maxks = 0;
+  if ((int)tiles.size() <= 4) {
+    // few n-tiles: split K across waves, members of a group are consecutive waves
+    std::vector<int> nm(tiles.size(), 1);
+    int used = (int)tiles.size();
+    while (used < CV_WAVES) {  // give the next wave to the tile with the most k-steps per member
+      int best = 0;
+      double bv = -1;
+      for (size_t t = 0; t < tiles.size(); ++t) {
+        const double v = (double)tiles[t].ks / nm[t];
+        if (v > bv && nm[t] < tiles[t].ks) { bv = v; best = (int)t; }
+      }
+      if (bv < 0) break;
+      nm[best]++;
+      used++;
+    }
+    int w = 0;
+    for (size_t t = 0; t < tiles.size(); ++t) {
+      for (int m = 0; m < nm[t]; ++m, ++w) {
+        FwdJob& J = F->job[w][0];
+        J.b = (signed char)tiles[t].b;
+        J.nt = (signed char)tiles[t].nt;
+        J.ks0 = (signed char)(tiles[t].ks * m / nm[t]);
+        J.ks1 = (signed char)(tiles[t].ks * (m + 1) / nm[t]);
+        J.grp = nm[t] > 1 ? (signed char)t : -1;
+        J.owner = m == 0;
+        J.member = (signed char)m;
+        J.nmember = (signed char)nm[t];
+        maxks = std::max(maxks, J.ks1 - J.ks0);
+        if (nm[t] > 1) F->n_red_groups = (int)tiles.size();
+      }
+    }
+  } else {
+    // longest-processing-time onto the 4 SIMDs (waves w and w+4 share a SIMD), <= 2 jobs per wave
+    std::sort(tiles.begin(), tiles.end(), [](const Tile& a, const Tile& b) { return a.ks > b.ks; });
+    int simd_load[4] = {0, 0, 0, 0}, njobs[CV_WAVES] = {0};
+    for (const Tile& t : tiles) {
+      int bw = -1;
+      for (int w = 0; w < CV_WAVES; ++w) {
+        if (njobs[w] >= 2) continue;
+        if (bw < 0) { bw = w; continue; }
+        const int a = simd_load[w & 3] * 4 + njobs[w], b = simd_load[bw & 3] * 4 + njobs[bw];
+        if (a < b) bw = w;
+      }
+      if (bw < 0) return fail(BNN_E_INVALID, "conv fwd plan: more than 16 n-tiles");
+      FwdJob& J = F->job[bw][njobs[bw]++];
+      J.b = (signed char)t.b;
+      J.nt = (signed char)t.nt;
+      J.ks0 = 0;
+      J.ks1 = (signed char)t.ks;
+      J.grp = -1;
+      J.owner = 1;
+      J.member = 0;
+      J.nmember = 1;
+      simd_load[bw & 3] += t.ks;
+      maxks = std::max(maxks, t.ks);
+    }
+  }
+  *ks_needed = maxks;
+  return 0;
+}
+
+// jobs of the role-specialised forward (one per compute wave): tiles whose K exceeds FW_KS k-steps
+// are split, then the longest jobs keep being split until all FW_NC compute waves have work.
+static int build_conv_fwd2_plan(const GroupArgs& A, const LayerDesc* layers, ConvFwd2Plan* F) {
+  *F = ConvFwd2Plan{};
+  for (int w = 0; w < FW_NC; ++w) F->job[w].b = -1;
+  struct Tile { int b, nt, ks, nm; };
+  std::vector<Tile> tiles;
+  int njobs = 0;
+  for (int b = 0; b < A.g.n_branch; ++b) {
+    const BranchDesc& br = A.g.br[b];
+    const LayerDesc& ly = layers[br.layer];
+    if (br.pool) F->has_pool = 1;
+    const int ks = (ly.taps * (br.cin_p / 8) + 3) / 4;
+    for (int n = 0; n < br.ntiles; ++n) {
+      const int nm = (ks + FW_KS - 1) / FW_KS;
+      tiles.push_back({b, n, ks, nm});
+      njobs += nm;
+    }
+  }
+  if (njobs > FW_NC) return fail(BNN_E_INVALID, "conv fwd plan: %d jobs exceed %d compute waves", njobs, FW_NC);
+  while (njobs < FW_NC) {
+    int best = -1;
+    double bv = 1.0;  // only split jobs with more than one k-step per member
+    for (size_t t = 0; t < tiles.size(); ++t) {
+      const double v = (double)tiles[t].ks / tiles[t].nm;
+      if (v > bv && tiles[t].nm < tiles[t].ks) { bv = v; best = (int)t; }
+    }
+    if (best < 0) break;
+    tiles[best].nm++;
+    njobs++;
+  }
+  int w = 0, ngrp = 0;
+  for (size_t t = 0; t < tiles.size(); ++t) {
+    for (int m = 0; m < tiles[t].nm; ++m, ++w) {
+      FwdJob& J = F->job[w];
+      J.b = (signed char)tiles[t].b;
+      J.nt = (signed char)tiles[t].nt;
+      J.ks0 = (signed char)(tiles[t].ks * m / tiles[t].nm);
+      J.ks1 = (signed char)(tiles[t].ks * (m + 1) / tiles[t].nm);
+      J.grp = tiles[t].nm > 1 ? (signed char)t : -1;
+      J.owner = m == 0;
+      J.member = (signed char)m;
+      J.nmember = (signed char)tiles[t].nm;
+      if (J.ks1 - J.ks0 > FW_KS) return fail(BNN_E_INVALID, "conv fwd plan: job with more than %d k-steps", FW_KS);
+    }
+    if (tiles[t].nm > 1) ngrp++;
+  }
+  F->n_red_groups = ngrp;
+  return 0;
+}
+
+static int launch_conv_fwd_dma(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  ConvFwd2Plan F;
+  BNN_TRY(build_conv_fwd2_plan(A, layers, &F));
+  if (const char* dbg = getenv("BNN_FWD_ABLATE")) A.pool_sel = atoi(dbg);  // timing experiments only (wrong results)
+  const int c8n = A.g.in_cin_p / 8;
+  if (c8n != 4 && c8n != 16) return fail(BNN_E_INVALID, "conv fwd: input of %d channels (need 32 or 128)", A.g.in_cin_p);
+  if ((A.g.L * c8n + 63) / 64 * 2 > 4 * FW_NL) return fail(BNN_E_INVALID, "conv fwd: window too large for the loader plan");
+  F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+  const int pbytes = IMG_ROWS * A.g.in_cin_p * 2;
+  const int lds = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + (F.n_red_groups > 0 ? FW_NC * 4 * 256 * 4 : 0);
+  const unsigned grid = (unsigned)(A.cg.S * F.nsplit);
+  ProfScope ps_(pf, PK_FWD, gi, st);
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_PLAIN>, lds));
+    conv_fwd_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_LRT>, lds));
+    conv_fwd_dma_kernel<EM_LRT><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
+  } else {
+    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_FLIPOUT>, lds));
+    conv_fwd_dma_kernel<EM_FLIPOUT><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_conv_fwd_bf(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  ConvFwdPlan F;
+  int ks = 0;
+  BNN_TRY(build_conv_fwd_plan(A, layers, &F, &ks));
+  int maxj = 0;
+  for (int w = 0; w < CV_WAVES; ++w) maxj = std::max(maxj, (F.job[w][0].b >= 0) + (F.job[w][1].b >= 0));
+  const bool one = maxj <= 1;
+  if ((one && ks > 5) || (!one && ks > 4))
+    return fail(BNN_E_INVALID, "conv fwd plan needs %d k-steps x %d jobs per wave (compiled: 5x1, 4x2)", ks, maxj);
+  if (A.g.L * (A.g.in_cin_p / 8) * 2 > 2 * CV_THREADS) return fail(BNN_E_INVALID, "conv fwd staging exceeds 2 units per thread");
+  F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+  const int pbytes = (IMG_ROWS * img_row_stride(A.g.in_cin_p, true) * 2 + 15) & ~15;
+  const int lds = 6 * pbytes + (F.n_red_groups > 0 ? CV_WAVES * 4 * 256 * 4 : 0);
+  const unsigned grid = (unsigned)(A.cg.S * F.nsplit);
+  ProfScope ps_(pf, PK_FWD, gi, st);
+#define LAUNCH_FWD(EMV)                                                                      \
+  do {                                                                                       \
+    if (one) {                                                                               \
+      BNN_TRY(set_lds(conv_fwd_bf_kernel<EMV, 5, 1>, lds));                                  \
+      conv_fwd_bf_kernel<EMV, 5, 1><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, F);        \
+    } else {                                                                                 \
+      BNN_TRY(set_lds(conv_fwd_bf_kernel<EMV, 4, 2>, lds));                                  \
+      conv_fwd_bf_kernel<EMV, 4, 2><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, F);        \
+    }                                                                                        \
+  } while (0)
+  if (em == EM_PLAIN) LAUNCH_FWD(EM_PLAIN);
+  else if (em == EM_LRT) LAUNCH_FWD(EM_LRT);
+  else LAUNCH_FWD(EM_FLIPOUT);
+#undef LAUNCH_FWD
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static void build_conv_dw_plan(const GroupArgs& A, const LayerDesc* layers, ConvDwPlan* D) {
   *D = ConvDwPlan{};
   int zo = 0, nt = 0;
@@ -822,8 +1020,8 @@ static int launch_conv_dw_bf_em(const GroupArgs& A, const ConvDwPlan& D, int lds
     BNN_TRY(set_lds(conv_dw_bf_kernel<EM, 6, 2, 3>, lds));
     conv_dw_bf_kernel<EM, 6, 2, 3><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
   } else {
-    BNN_TRY(set_lds(conv_dw_bf_kernel<EM, 10, 2, 3>, lds));
-    conv_dw_bf_kernel<EM, 10, 2, 3><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+    BNN_TRY(set_lds(conv_dw_bf_kernel<EM, 11, 2, 3>, lds));
+    conv_dw_bf_kernel<EM, 11, 2, 3><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -833,7 +1031,7 @@ static int launch_conv_dw_bf(const GroupArgs& A0, const LayerDesc* layers, int e
   GroupArgs A = A0;
   ConvDwPlan D;
   build_conv_dw_plan(A, layers, &D);
-  if (D.ntiles > 96 || (D.ntiles + CV_WAVES - 1) / CV_WAVES > 10) return fail(BNN_E_INVALID, "conv dW plan too large");
+  if (D.ntiles > 96 || (D.ntiles + CV_WAVES - 1) / CV_WAVES > 11) return fail(BNN_E_INVALID, "conv dW plan too large");
   D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
   const int xw16 = rup(A.g.in_cin_p, 16);
   const int xbytes = (IMG_ROWS * img_row_stride(xw16, true) * 2 + 15) & ~15;
@@ -850,11 +1048,21 @@ static int launch_conv_dw_bf(const GroupArgs& A0, const LayerDesc* layers, int e
 }
 
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
+  const bool bf = p->d.prec == BNN_PREC_BF16X3;
+  if (bf && p->d.net == BNN_NET_INCEPTION) {
+    const long rows = (long)c->B * p->d.win_length;
+    u16* xh = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
+    u16* xl = xh + (size_t)p->d.max_batch * p->d.win_length * 32;
+    x_planes_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xh, xl, rows, p->d.n_features, 32);
+    HIP_TRY(hipGetLastError());
+  }
   for (int gi = 0; gi < p->n_groups; ++gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, x, &A);
-    if (p->d.prec == BNN_PREC_F32)
+    if (!bf)
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
+    else if (!A.g.is_dense)
+      BNN_TRY((getenv("BNN_FWD_V2") ? launch_conv_fwd_bf : launch_conv_fwd_dma)(A, p->layers, c->em, c->st, &p->prof, gi));
     else
       BNN_TRY(launch_fwd<PrecBF>(A, c->em, c->st, &p->prof, gi));
   }

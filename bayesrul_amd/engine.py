@@ -176,7 +176,7 @@ class SviEngine:
         k = torch.arange(cin)
         if self.net == "inception" and name in ("layers.1.branch1.0", "layers.1.branch2.0", "layers.1.branch3.0",
                                                 "layers.1.branch4.1"):
-            return (k // 27) * 28 + k % 27          # block-1 branch outputs are stored 27 -> 28 padded
+            return (k // 27) * 32 + k % 27          # block-1 branch outputs are stored 27 -> 32 padded
         if self.net == "inception" and name == "layers.3":
             Lw = self.win_length
             return (k % Lw) * 80 + k // Lw          # nn.Flatten of [C=80, L]: c*L + l -> l*80 + c

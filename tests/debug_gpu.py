@@ -53,7 +53,7 @@ def run(net, mode, prec, S=2, B=3, q_boost=20.0):
                 return relu(cap[name]).permute(0, 2, 1).reshape(B * L, -1)
             rows = slice(s * B * L, (s + 1) * B * L)
             for bi, nm in enumerate(["layers.0.conv1.0", "layers.0.conv3.0", "layers.0.conv5.0", "layers.0.convpool.1"]):
-                print(f"   s{s} act1[{nm}] relerr {rel_l2(t1[rows, 28 * bi:28 * bi + 27], cl(nm)):.3e}  pad {float(t1[rows, 28 * bi + 27].abs().max()):.1e}")
+                print(f"   s{s} act1[{nm}] relerr {rel_l2(t1[rows, 32 * bi:32 * bi + 27], cl(nm)):.3e}  pad {float(t1[rows, 32 * bi + 27:32 * bi + 32].abs().max()):.1e}")
             print(f"   s{s} mid[b2.0] {rel_l2(tm[rows, :64], cl('layers.1.branch2.0')):.3e} mid[b3.0] {rel_l2(tm[rows, 64:], cl('layers.1.branch3.0')):.3e}")
             for nm, (a, b) in {"layers.1.branch1.0": (0, 16), "layers.1.branch2.2": (16, 32), "layers.1.branch3.2": (32, 48), "layers.1.branch4.1": (48, 80)}.items():
                 print(f"   s{s} act2[{nm}] {rel_l2(t2[rows, a:b], cl(nm)):.3e}")
