@@ -82,14 +82,16 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs 
     if (c + 4 > tin.ctot && x_ok[u]) x_ok[u] = (c < tin.ctot);  // partial handled in loader
   }
   int z_src[ZU], z_dst[ZU], z_nv[ZU];
-  int z_tg[ZU], z_ty[ZU], z_tq[ZU];   // tensor ids of dY / Y (relu mask; -1 none) / q (LRT)
+  const u16* z_g[ZU];   // bf16 planes resolved once: dY, Y hi (relu mask; null: none), q (LRT)
+  const u16* z_y[ZU];
+  const u16* z_q[ZU];
   int z_ct[ZU];
 #pragma unroll
   for (int u = 0; u < ZU; ++u) {
     const int unit = tid + u * CV_THREADS;
     z_nv[u] = 0;
     z_src[u] = z_dst[u] = z_ct[u] = 0;
-    z_tg[u] = z_ty[u] = z_tq[u] = -1;
+    z_g[u] = z_y[u] = z_q[u] = nullptr;
     if (unit < zunits) {
       const int row = unit / zc4, zc = (unit - row * zc4) * 4;
       int b = 0;
@@ -104,9 +106,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs 
         z_ct[u] = tg.ctot;
         z_src[u] = row * tg.ctot + br.out_off + c;
         z_dst[u] = (row + HALO) * RSz + zc;
-        z_tg[u] = br.out_t + T_GRAD;
-        z_ty[u] = br.relu ? br.out_t : -1;
-        z_tq[u] = LRT ? br.q_t : -1;
+        z_g[u] = (const u16*)tg.p;
+        z_y[u] = br.relu ? (const u16*)A.t[br.out_t].p : nullptr;
+        z_q[u] = LRT ? (const u16*)A.t[br.q_t].p : nullptr;
       }
     }
   }
@@ -161,8 +163,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs 
     for (int u = 0; u < XU; ++u) {
       px[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (x_ok[u]) {
-        const int c = x_src[u] % tin.ctot;
-        px[u] = tload4(tin, xrow0 * tin.ctot + x_src[u], tin.ctot - c, x_vec);
+        px[u] = unpack_bf4(*(const uint2*)((const u16*)tin.p + xrow0 * tin.ctot + x_src[u]));
       }
     }
 #pragma unroll
@@ -171,15 +172,14 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs 
       pq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (z_nv[u] > 0) {
         const long o = zrow0 * z_ct[u] + z_src[u];
-        const bool v = ((z_ct[u] & 3) == 0) && ((z_src[u] & 3) == 0);
-        f32x4 g = tload4(A.t[z_tg[u]], o, z_nv[u], v);
-        if (z_ty[u] >= 0) {
-          const f32x4 y = tload4(A.t[z_ty[u]], o, z_nv[u], v);
+        f32x4 g = unpack_bf4(*(const uint2*)(z_g[u] + o));   // channel pads of the tensors are zero
+        if (z_y[u]) {
+          const f32x4 y = unpack_bf4(*(const uint2*)(z_y[u] + o));
 #pragma unroll
           for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
         }
         pz[u] = g;
-        if constexpr (LRT) pq[u] = tload4(A.t[z_tq[u]], o, z_nv[u], v);
+        if constexpr (LRT) pq[u] = unpack_bf4(*(const uint2*)(z_q[u] + o));
       }
     }
     if constexpr (EM == EM_FLIPOUT) {
@@ -1189,6 +1189,365 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
               if constexpr (LRT) e_q[oo + r] = f2bf(qv[r]);
             }
         }
+      }
+    }
+  }
+}
+
+// ==========================================================================================
+// conv_dx_dma_kernel : gradient w.r.t. the input tensor of a conv group (or its pooled copy),
+// same role-specialised structure as conv_fwd_dma_kernel.
+//   loaders : DMA the dY / Y(hi) [/ q] channel slices of every selected branch (one dense,
+//             XOR-swizzled sub-image per branch and plane type) + the X hi plane for LRT, two
+//             windows ahead; every DMA instruction serves ONE (plane type, branch), so its source
+//             base is wave-uniform and the loader loop contains no ordinary load;
+//   all     : dz = dY * [Y > 0]   (LRT: dz2 = dz * q)  in LDS;
+//   compute : job = one 16-channel tile of the input tensor; K runs over the selected branches
+//             (transposed + flipped weight images, fragments in registers);
+//             dX = Wa^T dz + { LRT: 2 X (Wb^T dz2) | Flipout: s_in_b (Wb_b^T (dz s_out_b)) }.
+// ==========================================================================================
+enum { DX_KS = 5, DX_MAXB = 3, DX_MAXI = 40, DX_NC = 8, DX_THREADS = (DX_NC + FW_NL) * 64 };  // 12 waves: 170 VGPRs each
+
+struct DxInst {
+  signed char pt, b;     // plane type (0 dY, 1 Y, 2 q, 3 X) and branch
+  short q0;              // first 16-byte chunk of this instruction inside the sub-image
+};
+
+struct ConvDxPlan {
+  int nsplit, nks, ntile, pool_sel;
+  int zbase[BNN_MAX_BRANCH];      // element offset of branch b's sub-image inside a plane (-1: not selected)
+  int zelems;                     // elements of one plane (all sub-images, incl. halo rows)
+  int ninst;
+  signed char ks_b[DX_KS], ks_i[DX_KS], ks_slot[DX_KS], pad_;
+  DxInst inst[DX_MAXI];
+};
+
+#define BNN_WAIT_VMCNT(N)                                                     \
+  do {                                                                        \
+    switch (N) {                                                              \
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;         \
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;         \
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;         \
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;         \
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;         \
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;         \
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;         \
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;         \
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;         \
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;         \
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;       \
+      case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;       \
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;       \
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;        \
+    }                                                                         \
+  } while (0)
+
+// chunk position of channel chunk c8 in image row r of a dense image with cb8 chunks per row
+__device__ __forceinline__ int swz(int c8, int r, int cb8) {
+  return c8 ^ ((cb8 >= 16 ? r : (r / (16 / cb8))) & (cb8 - 1));
+}
+
+template <int EM>
+__global__ __launch_bounds__(DX_THREADS) void conv_dx_dma_kernel(const GroupArgs A, const ConvDxPlan D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool DUAL = (EM != EM_PLAIN);
+  constexpr bool LRT = (EM == EM_LRT);
+  constexpr int NPT = LRT ? 3 : 2;              // plane types per branch: dY, Y [, q]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GroupDesc& G = A.g;
+  const int s = blockIdx.x / D.nsplit, split = blockIdx.x - s * D.nsplit;
+  const int L = G.L, B = A.cg.B;
+  const int zbytes = D.zelems * 2;
+  const int xw = G.in_cin_p, x8n = xw >> 3;
+  const int xbytes = LRT ? IMG_ROWS * xw * 2 : 0;
+  const int slot_bytes = NPT * zbytes + xbytes;
+  // LDS: raw[FW_SLOTS][dY | Y | q | X] | dz | dz2 | sign words
+  u16* dzi = (u16*)(smem + FW_SLOTS * slot_bytes);
+  u16* dz2 = (u16*)(smem + FW_SLOTS * slot_bytes + zbytes);
+  uint32_t* sgn = (uint32_t*)(smem + FW_SLOTS * slot_bytes + 2 * zbytes);
+  {
+    const int total = (FW_SLOTS * slot_bytes + 2 * zbytes + FW_SLOTS * 64 * 4) >> 2;
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < total; k += DX_THREADS) z[k] = 0u;
+  }
+  const TensorRef tin = A.t[G.in_t];
+  const bool is_loader = wave >= DX_NC;
+  const int lw = wave - DX_NC;
+  const int my_ninst = is_loader ? max(0, (D.ninst - lw + FW_NL - 1) / FW_NL) : 0;
+  const int nwin = (B - split + D.nsplit - 1) / D.nsplit;
+  auto win_of = [&](int k) { return split + k * D.nsplit; };
+
+  int dx_t = -1;
+  for (int b = 0; b < G.n_branch; ++b)
+    if (D.zbase[b] >= 0) dx_t = G.br[b].dx_t;
+  const TensorRef tdx = A.t[dx_t];
+
+  // flipout sign words: [branch][8] = 4 words sign_in + 2 words sign_out (loader 0)
+  const uint32_t* sg_src = nullptr;
+  long sg_stride = 0;
+  bool sg_ok = false;
+  if (EM == EM_FLIPOUT && is_loader && lw == 0 && lane < 8 * G.n_branch) {
+    const int b = lane >> 3, k = lane & 7;
+    const BranchDesc& br = G.br[b];
+    const LayerDesc& ly = A.layers[br.layer];
+    if (k < 4 && k < ly.sign_in_words) {
+      sg_src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + k;
+      sg_stride = ly.sign_in_words;
+      sg_ok = true;
+    } else if (k >= 4 && k - 4 < ly.sign_out_words && k < 6) {
+      sg_src = A.nz.sign_out + ly.sign_out_off * A.nz.examples + (k - 4);
+      sg_stride = ly.sign_out_words;
+      sg_ok = true;
+    }
+  }
+  // everything about an instruction except the lane part is wave-uniform (scalar loads of the
+  // kernel arguments): no vector load in the loader loop
+  auto issue = [&](int k) {
+    const int wl = win_of(k);
+    const long w = (long)s * B + wl;
+    char* slot = smem + (k % FW_SLOTS) * slot_bytes;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    for (int i = 0; i < my_ninst; ++i) {
+      const DxInst I = D.inst[lw + i * FW_NL];
+      const int q = I.q0 + lane_o;
+      if (I.pt < 3) {
+        const BranchDesc& br = G.br[I.b];
+        const int cb8 = br.cout >> 3;
+        const int row = q / cb8, p = q - row * cb8;
+        const int c8 = swz(p, row + HALO, cb8);
+        const TensorRef tt = I.pt == 0 ? A.t[br.out_t + T_GRAD] : (I.pt == 1 ? A.t[br.out_t] : A.t[br.q_t]);
+        const u16* src = (const u16*)tt.p + (w * L + row) * tt.ctot + br.out_off + c8 * 8;
+        char* dst = slot + I.pt * zbytes + (D.zbase[I.b] + HALO * br.cout) * 2 + I.q0 * 16;
+        if (q < L * cb8) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
+      } else {
+        const int row = q / x8n, p = q - row * x8n;
+        const int c8 = swz(p, row + HALO, x8n);
+        const u16* src = (const u16*)tin.p + (w * L + row) * tin.ctot + c8 * 8;
+        char* dst = slot + NPT * zbytes + HALO * xw * 2 + I.q0 * 16;
+        if (q < L * x8n) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
+      }
+    }
+    if (EM == EM_FLIPOUT && lw == 0) {
+      if (sg_ok) dma4(sg_src + w * sg_stride, __builtin_amdgcn_readfirstlane(lds_addr(sgn + (k % FW_SLOTS) * 64)));
+    }
+  };
+  const int n_issue = my_ninst + ((EM == EM_FLIPOUT && lw == 0) ? 1 : 0);  // every instruction has active lanes
+
+  // =========================== compute state ===========================
+  const int i16 = lane & 15, g4 = lane >> 4;
+  bf16x8 w_a[DX_KS], w_b[DX_KS];
+  int k_pk[DX_KS];      // per lane: image row base (tap - pad + HALO) | channel chunk inside the branch << 8
+  bool k_on[DX_KS];     // wave-uniform: this k-step exists for this tile
+  const int ct = wave;  // compute wave w owns input-channel tile w
+  const bool has_job = !is_loader && ct < D.ntile;
+  int k_cb8[DX_KS], k_zb[DX_KS], k_slot[DX_KS], k_noff[DX_KS], k_bb[DX_KS];   // wave-uniform
+#pragma unroll
+  for (int ks = 0; ks < DX_KS; ++ks) {
+    w_a[ks] = w_b[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    k_on[ks] = false;
+    k_pk[ks] = HALO;
+    k_cb8[ks] = 1; k_zb[ks] = 0; k_slot[ks] = 0; k_noff[ks] = 0; k_bb[ks] = 0;
+    if (has_job && ks < D.nks) {
+      const int b = D.ks_b[ks];
+      const BranchDesc& br = G.br[b];
+      const LayerDesc& ly = A.layers[br.layer];
+      const int c0 = ct * 16 - br.in_off;                 // first layer-input channel of this tile
+      if (c0 >= 0 && c0 < br.cin_p) {
+        k_on[ks] = true;
+        const int G8 = ly.cout_p8 >> 3;                   // K groups per tap in the transposed image
+        const int gg = D.ks_i[ks] * 4 + g4;
+        const int tap = gg / G8, c8 = gg - tap * G8;
+        const bool valid = tap < ly.taps && c8 * 8 < br.cout;
+        const long wo = (long)(c0 + i16) * ly.KPt + (long)D.ks_i[ks] * 32 + g4 * 8;
+        const long sa = A.ws.slott_stride_a * s, sb = A.ws.slott_stride_b * s;
+        if (valid) {
+          w_a[ks] = *(const bf16x8*)((const u16*)A.ws.at + sa + ly.wt_off + wo);
+          if constexpr (DUAL) w_b[ks] = *(const bf16x8*)((const u16*)A.ws.bt + sb + ly.wt_off + wo);
+        }
+        k_pk[ks] = valid ? ((tap - ly.pad + HALO) | (c8 << 8)) : HALO;   // per lane (tap depends on g4)
+        k_cb8[ks] = br.cout >> 3;
+        k_zb[ks] = D.zbase[b];
+        k_slot[ks] = D.ks_slot[ks];
+        k_noff[ks] = br.n_off;
+        k_bb[ks] = b;
+      }
+    }
+  }
+  // flipout: per selected branch, the sign_in bits of this tile's 16 channels
+  int fo_branch[DX_MAXB], fo_c0[DX_MAXB];
+#pragma unroll
+  for (int q = 0; q < DX_MAXB; ++q) {
+    fo_branch[q] = -1;
+    fo_c0[q] = 0;
+  }
+  if (EM == EM_FLIPOUT && has_job) {
+    int q = 0;
+    for (int b = 0; b < G.n_branch; ++b)
+      if (D.zbase[b] >= 0 && q < DX_MAXB) {
+        const int c0 = ct * 16 - G.br[b].in_off;
+        if (c0 >= 0 && c0 < G.br[b].cin_p) {
+          fo_branch[q] = b;
+          fo_c0[q] = c0;
+        }
+        ++q;
+      }
+  }
+  const int och = ct * 16 + 4 * g4;   // channel of the target tensor held by this lane
+  const bool pool_x = D.pool_sel != 0;
+
+  // ---- mask pass plan: one 16-byte chunk per thread and pass (fixed per thread) ----
+  // unit U -> (branch, row, chunk): walk the selected branches
+  int m_o = -1, m_relu = 0;
+  {
+    int U = tid;
+    for (int b = 0; b < G.n_branch; ++b) {
+      if (D.zbase[b] < 0) continue;
+      const int cb8 = G.br[b].cout >> 3;
+      const int n = L * cb8;
+      if (U >= 0 && U < n) {
+        const int row = U / cb8, p = U - row * cb8;
+        m_o = D.zbase[b] + (row + HALO) * G.br[b].cout + p * 8;   // same position in dY / Y / q / dz images
+        m_relu = G.br[b].relu;
+        U = -1;
+      } else if (U >= n) {
+        U -= n;
+      }
+    }
+  }
+
+  __syncthreads();
+  if (is_loader) {
+    if (nwin > 0) issue(0);
+    if (nwin > 1) issue(1);
+  }
+
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  for (int k = 0; k < nwin; ++k) {
+    const int slotk = k % FW_SLOTS;
+    const u16* r_dy = (const u16*)(smem + slotk * slot_bytes);
+    const u16* r_y = r_dy + (zbytes >> 1);
+    const u16* r_q = r_dy + zbytes;
+    const u16* r_x = (const u16*)(smem + slotk * slot_bytes + NPT * zbytes);
+    if (is_loader) {
+      if (k + 1 < nwin) BNN_WAIT_VMCNT(n_issue);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();   // B1
+    // ---- dz = dY * [Y > 0] (, dz2 = dz * q) ----
+    if (m_o >= 0) {
+      uint4 g = *(const uint4*)&r_dy[m_o];
+      if (m_relu) {
+        const uint4 y = *(const uint4*)&r_y[m_o];
+        auto msk = [](uint32_t yy) {   // bf16 > 0  <=>  sign bit clear and not zero
+          const uint32_t lo = ((yy & 0x8000u) == 0 && (yy & 0x7fffu) != 0) ? 0xffffu : 0u;
+          const uint32_t hi = ((yy & 0x80000000u) == 0 && (yy & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+          return lo | hi;
+        };
+        g.x &= msk(y.x); g.y &= msk(y.y); g.z &= msk(y.z); g.w &= msk(y.w);
+      }
+      *(uint4*)&dzi[m_o] = g;
+      if constexpr (LRT) {
+        const uint4 qq = *(const uint4*)&r_q[m_o];
+        const uint32_t gg[4] = {g.x, g.y, g.z, g.w}, qv[4] = {qq.x, qq.y, qq.z, qq.w};
+        uint32_t out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = bf2f((u16)(gg[e] & 0xffff)) * bf2f((u16)(qv[e] & 0xffff));
+          const float a1 = bf2f((u16)(gg[e] >> 16)) * bf2f((u16)(qv[e] >> 16));
+          out[e] = (uint32_t)f2bf(a0) | ((uint32_t)f2bf(a1) << 16);
+        }
+        *(uint4*)&dz2[m_o] = make_uint4(out[0], out[1], out[2], out[3]);
+      }
+    }
+    lds_barrier();   // B2
+    if (is_loader) {
+      if (k + 2 < nwin) issue(k + 2);
+    }
+    // ---------------- MFMA ----------------
+    if (has_job) {
+      f32x4 acc_a[2], acc_b[DX_MAXB][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        acc_a[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < DX_MAXB; ++q) acc_b[q][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const uint32_t* sg = sgn + slotk * 64;
+#pragma unroll
+      for (int ks = 0; ks < DX_KS; ++ks) {
+        if (k_on[ks]) {
+          u32x4 fm = {0u, 0u, 0u, 0u};
+          if constexpr (EM == EM_FLIPOUT) {
+            // sign_out of the 8 couts of this lane group
+            const int n0 = k_noff[ks] + ((k_pk[ks] >> 8) & 0xff) * 8;
+            const uint32_t byte = (sg[k_bb[ks] * 8 + 4 + (n0 >> 5)] >> (n0 & 31)) & 0xffu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              fm[q] = (((byte >> (2 * q)) & 1u) << 15) | (((byte >> (2 * q + 1)) & 1u) << 31);
+          }
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const int rr = (k_pk[ks] & 0xff) + mt * 16 + i16;
+            const int o = k_zb[ks] + rr * (k_cb8[ks] * 8) + swz((k_pk[ks] >> 8) & 0xff, rr, k_cb8[ks]) * 8;
+            const bf16x8 bz = *(const bf16x8*)&dzi[o];
+            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_a[ks], bz, acc_a[mt], 0, 0, 0);
+            if constexpr (LRT) {
+              const bf16x8 b2 = *(const bf16x8*)&dz2[o];
+              acc_b[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], b2, acc_b[0][mt], 0, 0, 0);
+            } else if constexpr (EM == EM_FLIPOUT) {
+              const u32x4 xb = __builtin_bit_cast(u32x4, bz) ^ fm;
+#pragma unroll
+              for (int q = 0; q < DX_MAXB; ++q)
+                if (q == k_slot[ks])
+                  acc_b[q][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], __builtin_bit_cast(bf16x8, xb),
+                                                                        acc_b[q][mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // ---------------- epilogue ----------------
+      const int wl = win_of(k);
+      const long w = (long)s * B + wl;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 16 + i16;
+        if (row >= L) continue;
+        f32x4 v = acc_a[mt];
+        if constexpr (LRT) {
+          // + 2 * X * (Wb^T dz2), X = bf16 input (pooled for the pooled branch); 4 channels = half a chunk
+          auto xat = [&](int r) {
+            const int ri = r + HALO;
+            return unpack_bf4(*(const uint2*)&r_x[ri * xw + swz(och >> 3, ri, x8n) * 8 + (och & 7)]);
+          };
+          f32x4 xv = xat(row);
+          if (pool_x) {
+            if (row > 0) {
+              const f32x4 a = xat(row - 1);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) xv[r] = fmaxf(xv[r], a[r]);
+            }
+            if (row + 1 < L) {
+              const f32x4 a = xat(row + 1);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) xv[r] = fmaxf(xv[r], a[r]);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += 2.f * xv[r] * acc_b[0][mt][r];
+        } else if constexpr (EM == EM_FLIPOUT) {
+#pragma unroll
+          for (int q = 0; q < DX_MAXB; ++q) {
+            if (fo_branch[q] >= 0) {
+              const int cb = fo_c0[q] + 4 * g4;
+              const uint32_t bits = sg[fo_branch[q] * 8 + (cb >> 5)] >> (cb & 31);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += ((bits >> r) & 1u) ? -acc_b[q][mt][r] : acc_b[q][mt][r];
+            }
+          }
+        }
+        *(uint2*)((u16*)tdx.p + (w * L + row) * tdx.ctot + och) = pack_bf4(v);
       }
     }
   }

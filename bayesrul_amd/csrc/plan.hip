@@ -1047,6 +1047,78 @@ static int launch_conv_dw_bf(const GroupArgs& A0, const LayerDesc* layers, int e
   return launch_conv_dw_bf_em<EM_FLIPOUT>(A, D, lds, grid, st);
 }
 
+static int launch_conv_dx_dma(const GroupArgs& A0, const LayerDesc* layers, int em, int pool_sel, hipStream_t st, Prof* pf,
+                              int gi) {
+  GroupArgs A = A0;
+  ConvDxPlan D{};
+  D.pool_sel = pool_sel;
+  D.ntile = A.g.in_cin_p / 16;
+  const int L = A.g.L;
+  const int npt = em == EM_LRT ? 3 : 2;
+  int zel = 0, nks = 0, slot = 0, units = 0;
+  for (int b = 0; b < A.g.n_branch; ++b) {
+    const BranchDesc& br = A.g.br[b];
+    D.zbase[b] = -1;
+    if (br.pool != pool_sel || br.dx_t < 0) continue;
+    const LayerDesc& ly = layers[br.layer];
+    if (br.cout % 8 || (16 % (br.cout / 8)) != 0) return fail(BNN_E_INVALID, "conv dX: branch cout %d unsupported", br.cout);
+    if (slot >= DX_MAXB) return fail(BNN_E_INVALID, "conv dX: more than %d branches", DX_MAXB);
+    D.zbase[b] = zel;
+    zel += IMG_ROWS * br.cout;
+    units += L * (br.cout / 8);
+    const int ks = (ly.taps * (ly.cout_p8 / 8) + 3) / 4;
+    for (int i = 0; i < ks; ++i) {
+      if (nks >= DX_KS) return fail(BNN_E_INVALID, "conv dX: more than %d k-steps", DX_KS);
+      D.ks_b[nks] = (signed char)b;
+      D.ks_i[nks] = (signed char)i;
+      D.ks_slot[nks] = (signed char)slot;
+      ++nks;
+    }
+    ++slot;
+  }
+  if (slot == 0) return 0;
+  if (units > DX_THREADS) return fail(BNN_E_INVALID, "conv dX: mask pass needs %d units", units);
+  if (D.ntile > DX_NC) return fail(BNN_E_INVALID, "conv dX: %d tiles exceed the compute waves", D.ntile);
+  D.nks = nks;
+  D.zelems = zel;
+  int ni = 0;
+  for (int pt = 0; pt < npt; ++pt)
+    for (int b = 0; b < A.g.n_branch; ++b) {
+      if (D.zbase[b] < 0) continue;
+      if (pt == 1 && !A.g.br[b].relu) continue;
+      const int nchunk = L * (A.g.br[b].cout / 8);
+      for (int q0 = 0; q0 < nchunk; q0 += 64) {
+        if (ni >= DX_MAXI) return fail(BNN_E_INVALID, "conv dX: DMA table overflow");
+        D.inst[ni++] = DxInst{(signed char)pt, (signed char)b, (short)q0};
+      }
+    }
+  if (em == EM_LRT)
+    for (int q0 = 0; q0 < L * (A.g.in_cin_p / 8); q0 += 64) {
+      if (ni >= DX_MAXI) return fail(BNN_E_INVALID, "conv dX: DMA table overflow");
+      D.inst[ni++] = DxInst{3, 0, (short)q0};
+    }
+  D.ninst = ni;
+  if ((ni + FW_NL - 1) / FW_NL + 1 > 12) return fail(BNN_E_INVALID, "conv dX: too many DMA instructions per loader");
+  D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+  const int zbytes = zel * 2, xbytes = em == EM_LRT ? IMG_ROWS * A.g.in_cin_p * 2 : 0;
+  const int lds = FW_SLOTS * (npt * zbytes + xbytes) + 2 * zbytes + FW_SLOTS * 64 * 4;
+  if (lds > 160 * 1024) return fail(BNN_E_INVALID, "conv dX: %d bytes of LDS", lds);
+  const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
+  ProfScope ps_(pf, PK_DX, gi, st);
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(conv_dx_dma_kernel<EM_PLAIN>, lds));
+    conv_dx_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(DX_THREADS), lds, st>>>(A, D);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(conv_dx_dma_kernel<EM_LRT>, lds));
+    conv_dx_dma_kernel<EM_LRT><<<dim3(grid), dim3(DX_THREADS), lds, st>>>(A, D);
+  } else {
+    BNN_TRY(set_lds(conv_dx_dma_kernel<EM_FLIPOUT>, lds));
+    conv_dx_dma_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DX_THREADS), lds, st>>>(A, D);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
   if (bf && p->d.net == BNN_NET_INCEPTION) {
@@ -1107,15 +1179,20 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       if (A.g.br[b].dx_t < 0) continue;
       (A.g.br[b].pool ? any_pool : any_direct) = true;
     }
+    const bool conv_bf = p->d.prec == BNN_PREC_BF16X3 && !A.g.is_dense;
     if (any_direct) {
       if (p->d.prec == BNN_PREC_F32)
         BNN_TRY(launch_dx<PrecF32>(A, c->em, 0, c->st, &p->prof, gi));
+      else if (conv_bf)
+        BNN_TRY(launch_conv_dx_dma(A, p->layers, c->em, 0, c->st, &p->prof, gi));
       else
         BNN_TRY(launch_dx<PrecBF>(A, c->em, 0, c->st, &p->prof, gi));
     }
     if (any_pool) {
       if (p->d.prec == BNN_PREC_F32)
         BNN_TRY(launch_dx<PrecF32>(A, c->em, 1, c->st, &p->prof, gi));
+      else if (conv_bf)
+        BNN_TRY(launch_conv_dx_dma(A, p->layers, c->em, 1, c->st, &p->prof, gi));
       else
         BNN_TRY(launch_dx<PrecBF>(A, c->em, 1, c->st, &p->prof, gi));
       // scatter through the arg-max of MaxPool1d(3,1,1) into the direct gradient
@@ -1124,8 +1201,15 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       const int C = p->tens[tin].ctot, L = A.g.L;
       const long n = nwin * L * C;
       ProfScope ps_(&p->prof, PK_POOLBWD, gi, c->st);
-      pool_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(
-          A.t[tin], A.t[T_POOLGRAD], A.t[tin + T_GRAD], nwin, L, C);
+      if (p->d.prec == BNN_PREC_BF16X3 && (C % 8) == 0) {
+        const long n8 = nwin * L * (C / 8);
+        pool_bwd_bf_kernel<<<dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, c->st>>>(
+            (const u16*)A.t[tin].p, (const u16*)A.t[tin].lo, (const u16*)A.t[T_POOLGRAD].p,
+            (u16*)A.t[tin + T_GRAD].p, nwin, L, C);
+      } else {
+        pool_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(
+            A.t[tin], A.t[T_POOLGRAD], A.t[tin + T_GRAD], nwin, L, C);
+      }
       HIP_TRY(hipGetLastError());
     }
   }
