@@ -1552,3 +1552,270 @@ __global__ __launch_bounds__(DX_THREADS) void conv_dx_dma_kernel(const GroupArgs
     }
   }
 }
+
+// ==========================================================================================
+// dense_fwd_dma_kernel : variational forward of a dense (Linear) layer, bf16 planes.
+// One workgroup = one 32-row window of example rows (one particle); the K dimension is walked in
+// 128-channel chunks that the loader waves stream with LDS-DMA two chunks ahead.  Compute wave
+// (nt, m) owns n-tile nt and the chunks c = m (mod members): after its MFMAs on chunk c it
+// issues the weight-fragment loads of chunk c + members into the same registers, so they have
+// `members` iterations to arrive.  Partial sums of the members are reduced through LDS once per
+// window; Flipout input signs are per example ROW here (XOR masks per lane).
+// ==========================================================================================
+enum { DN_CH = 128, DN_ROWS = 32 };
+
+struct DenseFwdPlan {
+  int ntile;      // n-tiles of the branch (cout / 16)
+  int members;    // compute waves per n-tile
+  int nchunk;
+  int pad_;
+};
+
+template <int EM>
+__global__ __launch_bounds__(FW_THREADS) void dense_fwd_dma_kernel(const GroupArgs A, const DenseFwdPlan F) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool DUAL = (EM != EM_PLAIN);
+  constexpr bool LRT = (EM == EM_LRT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GroupDesc& G = A.g;
+  const BranchDesc& br = G.br[0];
+  const LayerDesc& ly = A.layers[br.layer];
+  const Win W = decode_win(G, A.cg, blockIdx.x);
+  const int s = W.s;
+  const int pbytes = DN_ROWS * DN_CH * 2;              // one plane of a chunk (dense rows, 256 B)
+  // LDS: raw[FW_SLOTS][hi | lo] | sq | sign words [FW_SLOTS][32 rows][4] | red
+  u16* raw = (u16*)smem;
+  u16* sqi = (u16*)(smem + FW_SLOTS * 2 * pbytes);
+  uint32_t* sgn = (uint32_t*)(smem + (FW_SLOTS * 2 + 1) * pbytes);
+  float* red = (float*)(smem + (FW_SLOTS * 2 + 1) * pbytes + FW_SLOTS * 128 * 4);
+  {
+    const int total = ((FW_SLOTS * 2 + 1) * pbytes + FW_SLOTS * 128 * 4) >> 2;
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < total; k += FW_THREADS) z[k] = 0u;
+  }
+  const TensorRef tin = A.t[G.in_t];
+  const bool is_loader = wave >= FW_NC;
+  const int lw = wave - FW_NC;
+  const int nchunk = F.nchunk;
+  // loaders: 2 planes x 16 instructions (32 rows x 16 chunks of 16 B), 8 per ... 4 per loader
+  auto issue = [&](int c) {
+    char* slot = smem + (c % FW_SLOTS) * 2 * pbytes;
+    const int cw8 = min(DN_CH, br.cin_p - c * DN_CH) >> 3;   // valid 16-byte chunks per row
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int inst = lw + i * FW_NL;                 // 0..31: plane = inst >> 4
+      const int plane = inst >> 4, q0 = (inst & 15) * 64;
+      const int q = q0 + lane_o;
+      const int row = q >> 4, p = q & 15;
+      const int c8 = p ^ (row & 15);
+      // rows beyond the last valid one re-read that row: every instruction keeps active lanes
+      // (the counted vmcnt wait relies on it); their results are never stored
+      const int srow = min(row, W.nvalid - 1);
+      const u16* src = (const u16*)(plane ? tin.lo : tin.p) + (long)(W.in_row0 + srow) * tin.ctot + c * DN_CH + c8 * 8;
+      char* dst = slot + plane * pbytes + q0 * 16;
+      if (c8 < cw8) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
+    }
+    if (EM == EM_FLIPOUT && lw < 2) {
+      // sign_in words of this chunk: lane -> (row, word): 128 lanes over loaders 0 and 1
+      const int q = lw * 64 + lane_o;
+      const int row = q >> 2, k = q & 3;
+      const int srow = min(row, W.nvalid - 1);
+      const uint32_t* src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + (long)(W.ex0 + srow) * ly.sign_in_words + c * 4 + k;
+      if (c * 4 + k < ly.sign_in_words)
+        dma4(src, __builtin_amdgcn_readfirstlane(lds_addr(sgn + (c % FW_SLOTS) * 128 + lw * 64)));
+    }
+  };
+  const int n_issue = 8 + ((EM == EM_FLIPOUT && lw < 2) ? 1 : 0);
+
+  // =========================== compute state ===========================
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int nt = wave / F.members, mem = wave - nt * F.members;
+  const bool has_job = !is_loader && nt < F.ntile;
+  bf16x8 w_hi[4], w_lo[4], w_b[4];
+  const long sa = A.ws.slot_stride_a * s, sb = A.ws.slot_stride_b * s;
+  auto load_w = [&](int c) {
+    const int nks = min(DN_CH, br.cin_p - c * DN_CH) >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      w_hi[ks] = w_lo[ks] = w_b[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (ks < nks) {
+        const long wo = (long)(br.n_off + nt * 16 + i16) * ly.KP + (long)c * DN_CH + ks * 32 + g4 * 8;
+        w_hi[ks] = *(const bf16x8*)((const u16*)A.ws.a_hi + sa + ly.w_off + wo);
+        w_lo[ks] = *(const bf16x8*)((const u16*)A.ws.a_lo + sa + ly.w_off + wo);
+        if constexpr (DUAL) w_b[ks] = *(const bf16x8*)((const u16*)A.ws.b + sb + ly.w_off + wo);
+      }
+    }
+  };
+  if (has_job && mem < nchunk) load_w(mem);
+  f32x4 acc_a[2], acc_b[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    acc_a[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc_b[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  __syncthreads();
+  if (is_loader) {
+    if (nchunk > 0) issue(0);
+    if (nchunk > 1) issue(1);
+  }
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  for (int c = 0; c < nchunk; ++c) {
+    const int slot = c % FW_SLOTS;
+    const u16* r_hi = raw + slot * pbytes;
+    const u16* r_lo = r_hi + (pbytes >> 1);
+    if (is_loader) {
+      if (c + 1 < nchunk) BNN_WAIT_VMCNT(n_issue);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();   // B1: chunk c visible, chunk c-1 consumed
+    if constexpr (LRT) {
+      // squares of the bf16 hi plane (what the variance contraction sees)
+      for (int U = tid; U < DN_ROWS * 16; U += FW_THREADS) {
+        const uint4 h = *(const uint4*)&r_hi[U * 8];
+        const uint32_t hh[4] = {h.x, h.y, h.z, h.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = bf2f((u16)(hh[e] & 0xffff)), b = bf2f((u16)(hh[e] >> 16));
+          o[e] = (uint32_t)f2bf(a * a) | ((uint32_t)f2bf(b * b) << 16);
+        }
+        *(uint4*)&sqi[U * 8] = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+      lds_barrier();  // B2
+    }
+    if (is_loader) {
+      if (c + 2 < nchunk) issue(c + 2);
+    }
+    if (has_job && (c % F.members) == mem) {
+      const int nks = min(DN_CH, br.cin_p - c * DN_CH) >> 5;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < nks) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const int rr = mt * 16 + i16;
+            const int o = rr * DN_CH + (((ks * 4 + g4) ^ (rr & 15)) * 8);
+            const bf16x8 bh = *(const bf16x8*)&r_hi[o];
+            const bf16x8 bl = *(const bf16x8*)&r_lo[o];
+            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bh, acc_a[mt], 0, 0, 0);
+            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bl, acc_a[mt], 0, 0, 0);
+            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[ks], bh, acc_a[mt], 0, 0, 0);
+            if constexpr (LRT) {
+              const bf16x8 b2 = *(const bf16x8*)&sqi[o];
+              acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], b2, acc_b[mt], 0, 0, 0);
+            } else if constexpr (EM == EM_FLIPOUT) {
+              // sign word of (row rr, k-step ks): byte g4 = this lane's 8 channels
+              const uint32_t word = sgn[slot * 128 + rr * 4 + ks];
+              const uint32_t byte = (word >> (8 * g4)) & 0xffu;
+              u32x4 fm;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                fm[q] = (((byte >> (2 * q)) & 1u) << 15) | (((byte >> (2 * q + 1)) & 1u) << 31);
+              const u32x4 xb = __builtin_bit_cast(u32x4, bh) ^ fm;
+              acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], __builtin_bit_cast(bf16x8, xb), acc_b[mt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (c + F.members < nchunk) load_w(c + F.members);   // lands while the other members work
+    }
+  }
+  // ---------------- reduction over the members of an n-tile ----------------
+  if (F.members > 1) {
+    if (has_job && mem > 0) {
+      float* r = red + (size_t)wave * (2 * 2 * 256);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        *(f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4] = acc_a[mt];
+        if constexpr (DUAL) *(f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4] = acc_b[mt];
+      }
+    }
+    lds_barrier();
+    if (has_job && mem == 0) {
+      for (int m = 1; m < F.members; ++m) {
+        const float* r = red + (size_t)(wave + m) * (2 * 2 * 256);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const f32x4 pa = *(const f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc_a[mt][q] += pa[q];
+          if constexpr (DUAL) {
+            const f32x4 pb = *(const f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc_b[mt][q] += pb[q];
+          }
+        }
+      }
+    }
+  }
+  // ---------------- epilogue (owner waves) ----------------
+  if (has_job && mem == 0) {
+    const int chb = nt * 16 + 4 * g4;
+    const int nv = br.cout - chb;
+    if (nv > 0) {
+      const TensorRef tout = A.t[br.out_t];
+      const float* ba = A.ws.bias_a + (long)A.ws.bias_stride_a * s + ly.bias_off + br.n_off + chb;
+      const float* bb = A.ws.bias_b + ly.bias_off + br.n_off + chb;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 16 + i16;
+        if (row >= W.nvalid) continue;
+        const int R = W.out_row0 + row;
+        f32x4 v = acc_a[mt];
+        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (LRT) {
+          f32x4 eps;
+          const int lch = br.n_off + chb;
+          if (A.nz.use_philox_lrt) {
+            const long Rg = global_row(A.cg, 1, R);
+            const uint64_t idx = (uint64_t)Rg * (uint64_t)(ly.cout_p16 >> 2) + (uint64_t)(lch >> 2);
+            eps = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)br.layer << 8), A.nz.step, A.nz.seed);
+          } else {
+            const float* e = A.nz.lrt_eps[br.layer] + (long)R * ly.cout + lch;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) eps[r] = (r < nv) ? e[r] : 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nv) {
+              const float loc = v[r] + ba[r];
+              float var = acc_b[mt][r] + bb[r];
+              if (var < 0.f) var = 1e-6f;
+              const float sd = sqrtf(var);
+              v[r] = loc + sd * eps[r];
+              qv[r] = sd > 0.f ? eps[r] / (2.f * sd) : 0.f;
+            }
+        } else if constexpr (EM == EM_FLIPOUT) {
+          const int bit0 = br.n_off + chb;
+          const uint32_t word = A.nz.sign_out[ly.sign_out_off * A.nz.examples + (long)(W.ex0 + row) * ly.sign_out_words + (bit0 >> 5)];
+          const uint32_t bits = word >> (bit0 & 31);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nv) {
+              const float pb = acc_b[mt][r];
+              v[r] = v[r] + ba[r] + (((bits >> r) & 1u) ? -pb : pb);
+            }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nv) v[r] += ba[r];
+        }
+        if (br.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        const long oo = (long)R * tout.ctot + br.out_off + chb;
+        const bool vec = ((tout.ctot & 3) == 0) && ((br.out_off & 3) == 0);
+        tstore4(tout, oo, v, nv, vec);
+        if constexpr (LRT) {
+          const TensorRef tq = A.t[br.q_t];
+          tstore4(tq, (long)R * tq.ctot + br.out_off + chb, qv, nv, vec);
+        }
+      }
+    }
+  }
+}

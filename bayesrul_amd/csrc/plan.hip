@@ -1119,6 +1119,39 @@ static int launch_conv_dx_dma(const GroupArgs& A0, const LayerDesc* layers, int 
   return 0;
 }
 
+// dense layers that fit the role-specialised kernel: one branch, bf16-plane input, cin multiple of 32
+static bool dense_dma_ok(const GroupArgs& A) {
+  if (!A.g.is_dense || A.g.n_branch != 1 || A.g.in_bcast) return false;
+  const BranchDesc& br = A.g.br[0];
+  if (A.t[A.g.in_t].fmt != TF_BF16 || A.t[A.g.in_t].lo == nullptr) return false;
+  return (br.cin_p % 32) == 0 && br.ntiles <= 4 && br.cin_real == br.cin_p && br.in_off == 0 && (A.t[A.g.in_t].ctot % 8) == 0;
+}
+
+static int launch_dense_fwd_dma(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  DenseFwdPlan F{};
+  const BranchDesc& br = A.g.br[0];
+  F.ntile = br.ntiles;
+  F.nchunk = (br.cin_p + DN_CH - 1) / DN_CH;
+  F.members = std::max(1, std::min(FW_NC / F.ntile, F.nchunk));
+  const int pbytes = DN_ROWS * DN_CH * 2;
+  const int lds = (FW_SLOTS * 2 + 1) * pbytes + FW_SLOTS * 128 * 4 + FW_NC * 4 * 256 * 4;
+  const unsigned grid = (unsigned)A.cg.nwin;
+  ProfScope ps_(pf, PK_FWD, gi, st);
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(dense_fwd_dma_kernel<EM_PLAIN>, lds));
+    dense_fwd_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(dense_fwd_dma_kernel<EM_LRT>, lds));
+    dense_fwd_dma_kernel<EM_LRT><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
+  } else {
+    BNN_TRY(set_lds(dense_fwd_dma_kernel<EM_FLIPOUT>, lds));
+    dense_fwd_dma_kernel<EM_FLIPOUT><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
   if (bf && p->d.net == BNN_NET_INCEPTION) {
@@ -1135,6 +1168,8 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
       BNN_TRY((getenv("BNN_FWD_V2") ? launch_conv_fwd_bf : launch_conv_fwd_dma)(A, p->layers, c->em, c->st, &p->prof, gi));
+    else if (dense_dma_ok(A))
+      BNN_TRY(launch_dense_fwd_dma(A, c->em, c->st, &p->prof, gi));
     else
       BNN_TRY(launch_fwd<PrecBF>(A, c->em, c->st, &p->prof, gi));
   }
