@@ -1819,3 +1819,116 @@ __global__ __launch_bounds__(FW_THREADS) void dense_fwd_dma_kernel(const GroupAr
     }
   }
 }
+
+// ==========================================================================================
+// dense_dx_bf_kernel : dX of a dense layer (K = cout <= 64 is tiny, the output is wide).
+// One workgroup = one 32-row window; dz (= dY [Y>0]) and its second image (LRT: dz*q, Flipout:
+// dz*s_out per row) are staged once into LDS; each of the 16 waves then walks its own 16-channel
+// output tiles independently (weights from L2, no barrier in the tile loop: latency is hidden by
+// the other waves).
+// ==========================================================================================
+template <int EM>
+__global__ __launch_bounds__(1024) void dense_dx_bf_kernel(const GroupArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool DUAL = (EM != EM_PLAIN);
+  constexpr bool LRT = (EM == EM_LRT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GroupDesc& G = A.g;
+  const BranchDesc& br = G.br[0];
+  const LayerDesc& ly = A.layers[br.layer];
+  const Win W = decode_win(G, A.cg, blockIdx.x);
+  const int s = W.s;
+  const int zw = (br.cout + 31) & ~31;          // K of the transposed contraction (multiple of 32)
+  const int RS = zw + 8;                        // (zw/8 is even) -> conflict-free b128 rows
+  u16* dz = (u16*)smem;
+  u16* dz2 = dz + DN_ROWS * RS;
+  const TensorRef tg = A.t[br.out_t + T_GRAD], ty = A.t[br.out_t], tq = A.t[br.q_t];
+  const TensorRef tin = A.t[G.in_t], tdx = A.t[br.dx_t];
+  // ---- stage dz / dz2 (4 channels per unit) ----
+  for (int U = tid; U < DN_ROWS * (zw >> 2); U += 1024) {
+    const int row = U / (zw >> 2), c = (U - row * (zw >> 2)) * 4;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
+    if (row < W.nvalid && c < br.cout) {
+      const long o = (long)(W.out_row0 + row) * tg.ctot + br.out_off + c;
+      const int nv = br.cout - c;
+      const bool vec = ((tg.ctot & 3) == 0) && ((br.out_off & 3) == 0);
+      g = tload4(tg, o, nv, vec);
+      if (br.relu) {
+        const f32x4 y = tload4(ty, o, nv, vec);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
+      }
+      if constexpr (LRT) {
+        const f32x4 q = tload4(tq, o, nv, vec);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g2[k] = g[k] * q[k];
+      } else if constexpr (EM == EM_FLIPOUT) {
+        const int bit0 = br.n_off + c;
+        const uint32_t word = A.nz.sign_out[ly.sign_out_off * A.nz.examples + (long)(W.ex0 + row) * ly.sign_out_words + (bit0 >> 5)];
+        const uint32_t bits = word >> (bit0 & 31);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g2[k] = ((bits >> k) & 1u) ? -g[k] : g[k];
+      }
+    }
+    *(uint2*)&dz[row * RS + c] = pack_bf4(g);
+    if constexpr (DUAL) *(uint2*)&dz2[row * RS + c] = pack_bf4(g2);
+  }
+  __syncthreads();
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int nks = zw >> 5;                       // 1 or 2 k-steps
+  // B fragments of the window (both m-tiles, all k-steps) stay in registers for every tile
+  bf16x8 bz[2][2], bz2[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      bz[ks][mt] = bz2[ks][mt] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (ks < nks) {
+        const int o = (mt * 16 + i16) * RS + ks * 32 + g4 * 8;
+        bz[ks][mt] = *(const bf16x8*)&dz[o];
+        if constexpr (DUAL) bz2[ks][mt] = *(const bf16x8*)&dz2[o];
+      }
+    }
+  const int ntile = br.cin_p >> 4;
+  const long sa = A.ws.slott_stride_a * s, sb = A.ws.slott_stride_b * s;
+  const u16* wat = (const u16*)A.ws.at + sa + ly.wt_off;
+  const u16* wbt = (const u16*)A.ws.bt + sb + ly.wt_off;
+  for (int t = wave; t < ntile; t += 16) {
+    const int c0 = t * 16;
+    f32x4 acc_a[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc_b[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks < nks) {
+        const long wo = (long)(c0 + i16) * ly.KPt + br.n_off + ks * 32 + g4 * 8;
+        const bf16x8 wa = *(const bf16x8*)(wat + wo);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bz[ks][mt], acc_a[mt], 0, 0, 0);
+        if constexpr (DUAL) {
+          const bf16x8 wb = *(const bf16x8*)(wbt + wo);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, bz2[ks][mt], acc_b[mt], 0, 0, 0);
+        }
+      }
+    }
+    const int och = c0 + 4 * g4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = mt * 16 + i16;
+      if (row >= W.nvalid) continue;
+      f32x4 v = acc_a[mt];
+      if constexpr (LRT) {
+        f32x4 xv = tload4(tin, (long)(W.in_row0 + row) * tin.ctot + br.in_off + och, 4, true);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += 2.f * bf2f(f2bf(xv[r])) * acc_b[mt][r];
+      } else if constexpr (EM == EM_FLIPOUT) {
+        const uint32_t word = A.nz.sign_in[ly.sign_in_off * A.nz.examples + (long)(W.ex0 + row) * ly.sign_in_words + (och >> 5)];
+        const uint32_t bits = word >> (och & 31);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += ((bits >> r) & 1u) ? -acc_b[mt][r] : acc_b[mt][r];
+      }
+      tstore4(tdx, (long)(W.in_row0 + row) * tdx.ctot + br.in_off + och, v, 4, true);
+    }
+  }
+}

@@ -1152,6 +1152,19 @@ static int launch_dense_fwd_dma(const GroupArgs& A0, int em, hipStream_t st, Pro
   return 0;
 }
 
+static int launch_dense_dx_bf(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  const int zw = rup(A.g.br[0].cout, 32);
+  const int lds = 2 * DN_ROWS * (zw + 8) * 2;
+  const unsigned grid = (unsigned)A.cg.nwin;
+  ProfScope ps_(pf, PK_DX, gi, st);
+  if (em == EM_PLAIN) dense_dx_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(1024), lds, st>>>(A);
+  else if (em == EM_LRT) dense_dx_bf_kernel<EM_LRT><<<dim3(grid), dim3(1024), lds, st>>>(A);
+  else dense_dx_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(1024), lds, st>>>(A);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
   if (bf && p->d.net == BNN_NET_INCEPTION) {
@@ -1220,6 +1233,9 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
         BNN_TRY(launch_dx<PrecF32>(A, c->em, 0, c->st, &p->prof, gi));
       else if (conv_bf)
         BNN_TRY(launch_conv_dx_dma(A, p->layers, c->em, 0, c->st, &p->prof, gi));
+      else if (A.g.is_dense && A.g.n_branch == 1 && A.g.br[0].cout <= 64 && (A.g.br[0].cin_p % 16) == 0 &&
+               A.g.br[0].cin_real == A.g.br[0].cin_p && (A.t[A.g.br[0].dx_t].ctot % 4) == 0)
+        BNN_TRY(launch_dense_dx_bf(A, c->em, c->st, &p->prof, gi));
       else
         BNN_TRY(launch_dx<PrecBF>(A, c->em, 0, c->st, &p->prof, gi));
     }
