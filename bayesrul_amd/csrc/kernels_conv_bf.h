@@ -1932,3 +1932,350 @@ __global__ __launch_bounds__(1024) void dense_dx_bf_kernel(const GroupArgs A) {
     }
   }
 }
+
+// ==========================================================================================
+// conv_dw_dma_kernel : dW of a conv group, role-specialised (8 compute waves + 4 LDS-DMA loaders).
+//   loaders : X hi plane + (dY, Y hi [, q]) sub-images of EVERY branch, two windows ahead;
+//   all     : dz = dY [Y>0] (LRT: dz2 = dz q), pooled X (max of bf16 is exact), LRT squares;
+//   compute : the dW tiles (branch, n-tile, tap, c-tile) of a wave stay in registers over all
+//             windows of the workgroup; operands through ds_read_b64_tr_b16 from the dense
+//             XOR-swizzled images; Flipout sign products are XORs on the fragments.
+// ==========================================================================================
+enum { DW_NC = 12, DW_THREADS = (DW_NC + FW_NL) * 64, DW_MAXT = 4, DW_KINDS = 2 };   // 16 waves: 128 VGPRs each
+
+// The branches of a group are dealt to DW_KINDS workgroup kinds: a workgroup stages X and the dz
+// sub-images of ITS branches only and keeps at most DW_MAXT dW tiles (x2 for LRT / Flipout) per
+// wave in registers.
+struct ConvDwSub {
+  int ntiles, ninst, has_pool, zelems;
+  int zbase[BNN_MAX_BRANCH];      // -1: branch not handled by this kind
+  DwTile tile[DW_NC * DW_MAXT];
+  DxInst inst[32];
+};
+struct ConvDw2Plan {
+  int nsplit, nslots, nkinds, pad_;
+  ConvDwSub sub[DW_KINDS];
+};
+
+template <int EM>
+__global__ __launch_bounds__(DW_THREADS) void conv_dw_dma_kernel(const GroupArgs A, const ConvDw2Plan DP) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool DUAL = (EM != EM_PLAIN);
+  constexpr bool LRT = (EM == EM_LRT);
+  constexpr int NPT = LRT ? 3 : 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GroupDesc& G = A.g;
+  const int kind = blockIdx.x % DP.nkinds;
+  const ConvDwSub& D = DP.sub[kind];
+  const int bid = blockIdx.x / DP.nkinds;
+  const int s = bid / DP.nsplit, split = bid - s * DP.nsplit;
+  const int L = G.L, B = A.cg.B;
+  const int xw = G.in_cin_p, x8n = xw >> 3;
+  const int xbytes = IMG_ROWS * xw * 2, zbytes = D.zelems * 2;
+  const int slot_bytes = xbytes + NPT * zbytes;
+  // LDS: raw[nslots][X | dY | Y | q] | derived (only what the estimator needs): dz | pooled X |
+  //      dz2 | X^2 | pooled X^2 | sign words
+  const int NS = DP.nslots;
+  char* der = smem + NS * slot_bytes;
+  int doff = 0;
+  u16* dzi = (u16*)(der + doff); doff += zbytes;
+  u16* xp = (u16*)(der + doff); doff += D.has_pool ? xbytes : 0;
+  u16* dz2 = (u16*)(der + doff); doff += LRT ? zbytes : 0;
+  u16* xsq = (u16*)(der + doff); doff += LRT ? xbytes : 0;
+  u16* xpsq = (u16*)(der + doff); doff += (LRT && D.has_pool) ? xbytes : 0;
+  uint32_t* sgn = (uint32_t*)(der + doff);
+  {
+    const int total = (NS * slot_bytes + doff + 3 * 64 * 4 + DW_NC * DW_MAXT * 16) >> 2;
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < total; k += DW_THREADS) z[k] = 0u;
+  }
+  const TensorRef tin = A.t[G.in_t];
+  const bool is_loader = wave >= DW_NC;
+  const int lw = wave - DW_NC;
+  const int my_ninst = is_loader ? max(0, (D.ninst - lw + FW_NL - 1) / FW_NL) : 0;
+  const int nwin = (B - split + DP.nsplit - 1) / DP.nsplit;
+  auto win_of = [&](int k) { return split + k * DP.nsplit; };
+
+  const uint32_t* sg_src = nullptr;
+  long sg_stride = 0;
+  bool sg_ok = false;
+  if (EM == EM_FLIPOUT && is_loader && lw == 0 && lane < 8 * G.n_branch) {
+    const int b = lane >> 3, k = lane & 7;
+    const BranchDesc& br = G.br[b];
+    const LayerDesc& ly = A.layers[br.layer];
+    if (k < 4 && k < ly.sign_in_words) {
+      sg_src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + k;
+      sg_stride = ly.sign_in_words;
+      sg_ok = true;
+    } else if (k >= 4 && k - 4 < ly.sign_out_words && k < 6) {
+      sg_src = A.nz.sign_out + ly.sign_out_off * A.nz.examples + (k - 4);
+      sg_stride = ly.sign_out_words;
+      sg_ok = true;
+    }
+  }
+  auto issue = [&](int k) {
+    const int wl = win_of(k);
+    const long w = (long)s * B + wl;
+    const long wx = G.in_bcast ? wl : w;
+    char* slot = smem + (k % NS) * slot_bytes;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    for (int i = 0; i < my_ninst; ++i) {
+      const DxInst I = D.inst[lw + i * FW_NL];
+      const int q = I.q0 + lane_o;
+      if (I.pt < 3) {
+        const BranchDesc& br = G.br[I.b];
+        const int cb8 = (br.cout + 7) >> 3;
+        const int row = q / cb8, p = q - row * cb8;
+        const int c8 = swz(p, row + HALO, cb8);
+        const TensorRef tt = I.pt == 0 ? A.t[br.out_t + T_GRAD] : (I.pt == 1 ? A.t[br.out_t] : A.t[br.q_t]);
+        const u16* src = (const u16*)tt.p + (w * L + row) * tt.ctot + br.out_off + c8 * 8;
+        char* dst = slot + xbytes + I.pt * zbytes + (D.zbase[I.b] + HALO * cb8 * 8) * 2 + I.q0 * 16;
+        if (q < L * cb8) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
+      } else {
+        const int row = q / x8n, p = q - row * x8n;
+        const int c8 = swz(p, row + HALO, x8n);
+        const u16* src = (const u16*)tin.p + (wx * L + row) * tin.ctot + c8 * 8;
+        char* dst = slot + HALO * xw * 2 + I.q0 * 16;
+        if (q < L * x8n) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
+      }
+    }
+    if (EM == EM_FLIPOUT && lw == 0) {
+      if (sg_ok) dma4(sg_src + w * sg_stride, __builtin_amdgcn_readfirstlane(lds_addr(sgn + (k % NS) * 64)));
+    }
+  };
+  const int n_issue = my_ninst + ((EM == EM_FLIPOUT && lw == 0) ? 1 : 0);
+
+  // ---- per-thread derive plan: up to 2 dz units and 1 X unit (16 bytes each) ----
+  int m_o[2] = {-1, -1}, m_relu[2] = {0, 0};
+  {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int U = tid + u * DW_THREADS;
+      for (int b = 0; b < G.n_branch; ++b) {
+        if (D.zbase[b] < 0) continue;
+        const int cb8 = (G.br[b].cout + 7) >> 3;
+        const int n = L * cb8;
+        if (U >= 0 && U < n) {
+          const int row = U / cb8, p = U - row * cb8;
+          m_o[u] = D.zbase[b] + (row + HALO) * cb8 * 8 + p * 8;
+          m_relu[u] = G.br[b].relu;
+          U = -1;
+        } else if (U >= n) {
+          U -= n;
+        }
+      }
+    }
+  }
+  const int x_units = L * x8n;
+
+  // ---- tiles of this compute wave: accumulators in registers, metadata in LDS (wave-uniform reads) ----
+  f32x4 acc_a[DW_MAXT], acc_b[DW_MAXT];
+  int* tmeta = (int*)(sgn + 3 * 64);   // [ntiles][4]: geo | zbase | sign_out word/bit | sign_in word/bit
+#pragma unroll
+  for (int m = 0; m < DW_MAXT; ++m) {
+    acc_a[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc_b[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();   // zero fill done before the table is written
+  for (int t = tid; t < D.ntiles; t += DW_THREADS) {
+    const DwTile T = D.tile[t];
+    const BranchDesc& br = G.br[T.b];
+    const LayerDesc& ly = A.layers[br.layer];
+    const int cb8 = (br.cout + 7) >> 3;
+    const int nbit = br.n_off + T.nt * 16, cbit = T.ct * 16;
+    tmeta[t * 4 + 0] = cb8 | ((T.nt * 16) << 8) | ((br.in_off + T.ct * 16) << 16) | ((T.tap - ly.pad + 8) << 24) | (br.pool << 30);
+    tmeta[t * 4 + 1] = D.zbase[T.b];
+    tmeta[t * 4 + 2] = (T.b * 8 + 4 + (nbit >> 5)) | ((nbit & 31) << 8);
+    tmeta[t * 4 + 3] = (T.b * 8 + (cbit >> 5)) | ((cbit & 31) << 8);
+  }
+  float gb_a = 0.f, gb_b = 0.f;
+  // bias-gradient plan: thread tid < total couts sums one dz column
+  int bz_zb = -1, bz_cb8 = 1, bz_n = 0, bz_b = 0;
+  {
+    int U = tid;
+    for (int b = 0; b < G.n_branch; ++b) {
+      if (D.zbase[b] < 0) continue;
+      if (U >= 0 && U < G.br[b].cout) {
+        bz_zb = D.zbase[b];
+        bz_cb8 = (G.br[b].cout + 7) >> 3;
+        bz_n = U;
+        bz_b = b;
+        U = -1;
+      } else if (U >= G.br[b].cout) {
+        U -= G.br[b].cout;
+      }
+    }
+  }
+
+  __syncthreads();
+  const int ahead = NS - 1;
+  if (is_loader) {
+    for (int k = 0; k < ahead && k < nwin; ++k) issue(k);
+  }
+  const int gq = lane >> 4, qq = (lane >> 2) & 3, pq = lane & 3;
+  for (int k = 0; k < nwin; ++k) {
+    const int slotk = k % NS;
+    const u16* r_x = (const u16*)(smem + slotk * slot_bytes);
+    const u16* r_dy = (const u16*)(smem + slotk * slot_bytes + xbytes);
+    const u16* r_y = r_dy + (zbytes >> 1);
+    const u16* r_q = r_dy + zbytes;
+    if (is_loader) {
+      // windows k+1 .. k+ahead-1 may stay in flight
+      const int fly = min(ahead - 1, nwin - 1 - k);
+      if (fly >= 1) BNN_WAIT_VMCNT(n_issue);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    lds_barrier();   // B1
+    // ---- derive: dz (, dz2), pooled X, squares ----
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (m_o[u] >= 0) {
+        uint4 g = *(const uint4*)&r_dy[m_o[u]];
+        if (m_relu[u]) {
+          const uint4 y = *(const uint4*)&r_y[m_o[u]];
+          auto msk = [](uint32_t yy) {
+            const uint32_t lo = ((yy & 0x8000u) == 0 && (yy & 0x7fffu) != 0) ? 0xffffu : 0u;
+            const uint32_t hi = ((yy & 0x80000000u) == 0 && (yy & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+            return lo | hi;
+          };
+          g.x &= msk(y.x); g.y &= msk(y.y); g.z &= msk(y.z); g.w &= msk(y.w);
+        }
+        *(uint4*)&dzi[m_o[u]] = g;
+        if constexpr (LRT) {
+          const uint4 q4 = *(const uint4*)&r_q[m_o[u]];
+          const uint32_t gg[4] = {g.x, g.y, g.z, g.w}, qv[4] = {q4.x, q4.y, q4.z, q4.w};
+          uint32_t out[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a0 = bf2f((u16)(gg[e] & 0xffff)) * bf2f((u16)(qv[e] & 0xffff));
+            const float a1 = bf2f((u16)(gg[e] >> 16)) * bf2f((u16)(qv[e] >> 16));
+            out[e] = (uint32_t)f2bf(a0) | ((uint32_t)f2bf(a1) << 16);
+          }
+          *(uint4*)&dz2[m_o[u]] = make_uint4(out[0], out[1], out[2], out[3]);
+        }
+      }
+    }
+    if (D.has_pool || LRT) {
+      for (int U = tid; U < x_units; U += DW_THREADS) {
+        const int row = U / x8n, p = U - row * x8n;
+        const int ri = row + HALO;
+        const int c8 = swz(p, ri, x8n) ;   // involution: channel chunk stored at position p
+        const int o = ri * xw + p * 8;
+        const uint4 h0 = *(const uint4*)&r_x[o];
+        uint32_t hh[4] = {h0.x, h0.y, h0.z, h0.w};
+        uint32_t pm[4] = {hh[0], hh[1], hh[2], hh[3]};
+        if (D.has_pool) {
+          auto mx = [](uint32_t a, uint32_t b) {
+            const float a0 = bf2f((u16)(a & 0xffff)), b0 = bf2f((u16)(b & 0xffff));
+            const float a1 = bf2f((u16)(a >> 16)), b1 = bf2f((u16)(b >> 16));
+            return (uint32_t)f2bf(fmaxf(a0, b0)) | ((uint32_t)f2bf(fmaxf(a1, b1)) << 16);
+          };
+          if (row > 0) {
+            const uint4 a = *(const uint4*)&r_x[(ri - 1) * xw + swz(c8, ri - 1, x8n) * 8];
+            pm[0] = mx(pm[0], a.x); pm[1] = mx(pm[1], a.y); pm[2] = mx(pm[2], a.z); pm[3] = mx(pm[3], a.w);
+          }
+          if (row + 1 < L) {
+            const uint4 a = *(const uint4*)&r_x[(ri + 1) * xw + swz(c8, ri + 1, x8n) * 8];
+            pm[0] = mx(pm[0], a.x); pm[1] = mx(pm[1], a.y); pm[2] = mx(pm[2], a.z); pm[3] = mx(pm[3], a.w);
+          }
+          *(uint4*)&xp[o] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        }
+        if constexpr (LRT) {
+          auto sq = [](uint32_t a) {
+            const float a0 = bf2f((u16)(a & 0xffff)), a1 = bf2f((u16)(a >> 16));
+            return (uint32_t)f2bf(a0 * a0) | ((uint32_t)f2bf(a1 * a1) << 16);
+          };
+          *(uint4*)&xsq[o] = make_uint4(sq(hh[0]), sq(hh[1]), sq(hh[2]), sq(hh[3]));
+          if (D.has_pool) *(uint4*)&xpsq[o] = make_uint4(sq(pm[0]), sq(pm[1]), sq(pm[2]), sq(pm[3]));
+        }
+      }
+    }
+    lds_barrier();   // B2
+    if (is_loader) {
+      if (k + ahead < nwin) issue(k + ahead);
+    }
+    // ---------------- tiles ----------------
+    if (!is_loader) {
+      const uint32_t* sg = sgn + slotk * 64;
+#pragma unroll
+      for (int m = 0; m < DW_MAXT; ++m) {
+        const int tix = wave + DW_NC * m;
+        if (tix < D.ntiles) {
+          const int geo = __builtin_amdgcn_readfirstlane(tmeta[tix * 4 + 0]);
+          const int tzb = __builtin_amdgcn_readfirstlane(tmeta[tix * 4 + 1]);
+          const int tso = __builtin_amdgcn_readfirstlane(tmeta[tix * 4 + 2]);
+          const int tsi = __builtin_amdgcn_readfirstlane(tmeta[tix * 4 + 3]);
+          const int cb8 = geo & 0xff, n0 = (geo >> 8) & 0xff, c0 = (geo >> 16) & 0xff;
+          const int tshift = ((geo >> 24) & 0x3f) - 8, pooled = (geo >> 30) & 1;
+          // lane 16g+4q+p: row (8g+q [+4]), columns 4p..4p+3 of the 16-column block
+          const int ra = 8 * gq + qq + HALO, rb = ra + tshift;
+          const int na = n0 + 4 * pq, cbx = c0 + 4 * pq;
+          const int zrow = cb8 * 8;
+          const u16* zi = dzi + tzb;
+          const u16* xi = pooled ? xp : r_x;
+          const u16* a0 = zi + ra * zrow + swz(na >> 3, ra, cb8) * 8 + (na & 7);
+          const u16* a1 = zi + (ra + 4) * zrow + swz(na >> 3, ra + 4, cb8) * 8 + (na & 7);
+          const u16* b0 = xi + rb * xw + swz(cbx >> 3, rb, x8n) * 8 + (cbx & 7);
+          const u16* b1 = xi + (rb + 4) * xw + swz(cbx >> 3, rb + 4, x8n) * 8 + (cbx & 7);
+          const bf16x8 fa = tr_frag(a0, a1);
+          const bf16x8 fb = tr_frag(b0, b1);
+          acc_a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc_a[m], 0, 0, 0);
+          if constexpr (LRT) {
+            const u16* z2 = dz2 + tzb;
+            const u16* xs = pooled ? xpsq : xsq;
+            const long da = a0 - zi, da1 = a1 - zi, db = b0 - xi, db1 = b1 - xi;
+            acc_b[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(z2 + da, z2 + da1), tr_frag(xs + db, xs + db1),
+                                                               acc_b[m], 0, 0, 0);
+          } else if constexpr (EM == EM_FLIPOUT) {
+            const bool no = (sg[tso & 0xff] >> ((tso >> 8) + (lane & 15))) & 1u;
+            const bool ni = (sg[tsi & 0xff] >> ((tsi >> 8) + (lane & 15))) & 1u;
+            acc_b[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xor_sign(fa, no), xor_sign(fb, ni), acc_b[m], 0, 0, 0);
+          }
+        }
+      }
+      if (bz_zb >= 0) {
+        float sa = 0.f, sb = 0.f;
+        const int zrow = bz_cb8 * 8;
+        for (int r = 0; r < L; ++r) {
+          const int ri = r + HALO;
+          const int o = bz_zb + ri * zrow + swz(bz_n >> 3, ri, bz_cb8) * 8 + (bz_n & 7);
+          sa += bf2f(dzi[o]);
+          if constexpr (LRT) sb += bf2f(dz2[o]);
+        }
+        gb_a += sa;
+        gb_b += sb;
+      }
+    }
+  }
+  // ---- write out ----
+  if (!is_loader) {
+    const int i4 = 4 * (lane >> 4), jc = lane & 15;
+#pragma unroll
+    for (int m = 0; m < DW_MAXT; ++m) {
+      if (wave + DW_NC * m >= D.ntiles) continue;
+      const DwTile T = D.tile[wave + DW_NC * m];
+      const BranchDesc& br = G.br[T.b];
+      const LayerDesc& ly = A.layers[br.layer];
+      const int c = T.ct * 16 + jc;
+      if (c >= br.cin_p) continue;
+      float* gwa = A.gw_a + A.gw_stride * s + ly.w_off;
+      float* gwb = A.gw_b + A.gw_stride * s + ly.w_off;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = T.nt * 16 + i4 + r;
+        if (n >= br.cout) continue;
+        const long o = (long)(br.n_off + n) * ly.KP + (long)T.tap * ly.cin_img + c;
+        atomicAdd(gwa + o, acc_a[m][r]);
+        if constexpr (DUAL) atomicAdd(gwb + o, acc_b[m][r]);
+      }
+    }
+    if (bz_zb >= 0) {
+      const BranchDesc& br = G.br[bz_b];
+      const LayerDesc& ly = A.layers[br.layer];
+      atomicAdd(A.gb_a + (long)A.gb_stride * s + ly.bias_off + br.n_off + bz_n, gb_a);
+      if constexpr (LRT) atomicAdd(A.gb_b + (long)A.gb_stride * s + ly.bias_off + br.n_off + bz_n, gb_b);
+    }
+  }
+}

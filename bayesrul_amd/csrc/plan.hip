@@ -1047,6 +1047,94 @@ static int launch_conv_dw_bf(const GroupArgs& A0, const LayerDesc* layers, int e
   return launch_conv_dw_bf_em<EM_FLIPOUT>(A, D, lds, grid, st);
 }
 
+static int launch_conv_dw_dma(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  static thread_local ConvDw2Plan D;   // large; copied into the kernel arguments at launch
+  D = ConvDw2Plan{};
+  const int L = A.g.L, npt = em == EM_LRT ? 3 : 2;
+  const int x8n = A.g.in_cin_p / 8;
+  if (x8n != 4 && x8n != 16) return fail(BNN_E_INVALID, "conv dW: input of %d channels", A.g.in_cin_p);
+  // deal the branches to the kinds: heaviest first onto the lighter kind
+  int ntile_b[BNN_MAX_BRANCH], order[BNN_MAX_BRANCH], load[DW_KINDS] = {0, 0}, kind_of[BNN_MAX_BRANCH];
+  for (int b = 0; b < A.g.n_branch; ++b) {
+    const BranchDesc& br = A.g.br[b];
+    ntile_b[b] = br.ntiles * layers[br.layer].taps * ((br.cin_p + 15) / 16);
+    order[b] = b;
+  }
+  std::sort(order, order + A.g.n_branch, [&](int x, int y) { return ntile_b[x] > ntile_b[y]; });
+  D.nkinds = A.g.n_branch > 1 ? DW_KINDS : 1;
+  for (int i = 0; i < A.g.n_branch; ++i) {
+    const int b = order[i];
+    const int k = (D.nkinds > 1 && load[1] < load[0]) ? 1 : 0;
+    kind_of[b] = k;
+    load[k] += ntile_b[b];
+  }
+  int lds_max = 0, slot_max = 0, der_max = 0;
+  for (int k = 0; k < D.nkinds; ++k) {
+    ConvDwSub& S = D.sub[k];
+    int zel = 0, nt = 0, ni = 0, units = 0;
+    for (int b = 0; b < A.g.n_branch; ++b) {
+      const BranchDesc& br = A.g.br[b];
+      const LayerDesc& ly = layers[br.layer];
+      S.zbase[b] = -1;
+      if (kind_of[b] != k) continue;
+      const int cb8 = (br.cout + 7) / 8;
+      if (16 % cb8) return fail(BNN_E_INVALID, "conv dW: branch cout %d unsupported", br.cout);
+      S.zbase[b] = zel;
+      zel += IMG_ROWS * cb8 * 8;
+      units += L * cb8;
+      if (br.pool) S.has_pool = 1;
+      const int ctiles = (br.cin_p + 15) / 16;
+      for (int n = 0; n < br.ntiles; ++n)
+        for (int t = 0; t < ly.taps; ++t)
+          for (int c = 0; c < ctiles; ++c) {
+            if (nt >= DW_NC * DW_MAXT) return fail(BNN_E_INVALID, "conv dW: more than %d tiles per workgroup kind", DW_NC * DW_MAXT);
+            S.tile[nt++] = DwTile{(signed char)b, (signed char)n, (signed char)t, (signed char)c};
+          }
+    }
+    S.ntiles = nt;
+    S.zelems = zel;
+    for (int q0 = 0; q0 < L * x8n; q0 += 64) S.inst[ni++] = DxInst{3, 0, (short)q0};
+    for (int pt = 0; pt < npt; ++pt)
+      for (int b = 0; b < A.g.n_branch; ++b) {
+        if (S.zbase[b] < 0 || (pt == 1 && !A.g.br[b].relu)) continue;
+        const int nchunk = L * ((A.g.br[b].cout + 7) / 8);
+        for (int q0 = 0; q0 < nchunk; q0 += 64) {
+          if (ni >= 32) return fail(BNN_E_INVALID, "conv dW: DMA table overflow");
+          S.inst[ni++] = DxInst{(signed char)pt, (signed char)b, (short)q0};
+        }
+      }
+    S.ninst = ni;
+    if ((ni + FW_NL - 1) / FW_NL + 1 > 12) return fail(BNN_E_INVALID, "conv dW: too many DMA instructions per loader");
+    if (units > 2 * DW_THREADS) return fail(BNN_E_INVALID, "conv dW: derive plan too large");
+    const int xbytes = IMG_ROWS * A.g.in_cin_p * 2, zbytes = zel * 2;
+    const int slot_bytes = xbytes + npt * zbytes;
+    const int der = zbytes + (S.has_pool ? xbytes : 0) + (em == EM_LRT ? zbytes + xbytes + (S.has_pool ? xbytes : 0) : 0) +
+                    3 * 64 * 4 + DW_NC * DW_MAXT * 16;
+    slot_max = std::max(slot_max, slot_bytes);
+    der_max = std::max(der_max, der);
+  }
+  D.nslots = (3 * slot_max + der_max > 160 * 1024) ? 2 : 3;
+  lds_max = D.nslots * slot_max + der_max;
+  if (lds_max > 160 * 1024) return fail(BNN_E_INVALID, "conv dW: %d bytes of LDS", lds_max);
+  D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+  const unsigned grid = (unsigned)(D.nkinds * A.cg.S * D.nsplit);
+  const int lds = lds_max;
+  ProfScope ps_(pf, PK_DW, gi, st);
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(conv_dw_dma_kernel<EM_PLAIN>, lds));
+    conv_dw_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(DW_THREADS), lds, st>>>(A, D);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(conv_dw_dma_kernel<EM_LRT>, lds));
+    conv_dw_dma_kernel<EM_LRT><<<dim3(grid), dim3(DW_THREADS), lds, st>>>(A, D);
+  } else {
+    BNN_TRY(set_lds(conv_dw_dma_kernel<EM_FLIPOUT>, lds));
+    conv_dw_dma_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DW_THREADS), lds, st>>>(A, D);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int launch_conv_dx_dma(const GroupArgs& A0, const LayerDesc* layers, int em, int pool_sel, hipStream_t st, Prof* pf,
                               int gi) {
   GroupArgs A = A0;
@@ -1180,7 +1268,7 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
     if (!bf)
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
-      BNN_TRY((getenv("BNN_FWD_V2") ? launch_conv_fwd_bf : launch_conv_fwd_dma)(A, p->layers, c->em, c->st, &p->prof, gi));
+      BNN_TRY((getenv("BNN_FWD_REGSTAGE") ? launch_conv_fwd_bf : launch_conv_fwd_dma)(A, p->layers, c->em, c->st, &p->prof, gi));
     else if (dense_dma_ok(A))
       BNN_TRY(launch_dense_fwd_dma(A, c->em, c->st, &p->prof, gi));
     else
@@ -1219,7 +1307,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
     else if (!A.g.is_dense)
-      BNN_TRY(launch_conv_dw_bf(A, p->layers, c->em, c->st, &p->prof, gi));
+      BNN_TRY((getenv("BNN_DW_DMA") ? launch_conv_dw_dma : launch_conv_dw_bf)(A, p->layers, c->em, c->st, &p->prof, gi));
     else
       BNN_TRY((launch_dw<PrecBF, 4>(A, c->em, c->st, &p->prof, gi)));
     bool any_direct = false, any_pool = false;
