@@ -39,7 +39,22 @@ GROUP_MACS = {
                   2400 * 64, 64 * 2],
     "linear": [540 * 256, 256 * 128, 128 * 128, 128 * 32, 32 * 2],
 }
-# which groups produce a dX (group 0 reads the input windows: no dX)
+# algorithmic HBM bytes per MC-sample x window of each (kernel kind, branch group), Inception with
+# bf16-plane storage (activation = hi + lo planes = 4 B/elem forward, hi only = 2 B/elem backward;
+# gradients 2 B/elem): read + written, LRT adds a q plane
+def group_bytes(net, kind, grp, em, S):
+    if net != "inception":
+        return None
+    L = 30
+    q = 2 if em == 1 else 0  # bytes/elem of the LRT q plane
+    fwd = [L * 32 * 4 / S + L * 128 * (4 + q), L * 128 * 4 + L * 176 * (4 + q), L * 128 * 4 + L * 32 * (4 + q),
+           L * 80 * 4 + 64 * (4 + q), 64 * 4 + 2 * 4]
+    dx = [0, L * 176 * (4 + q) + 2 * L * 128 * 2, L * 32 * (4 + q) + L * 128 * 2, 64 * (4 + q) + L * 80 * 2, 2 * 8 + 64 * 2]
+    dw = [L * 32 * 2 / S + L * 128 * (4 + q), L * 128 * 2 + L * 176 * (4 + q), L * 128 * 2 + L * 32 * (4 + q),
+          L * 80 * 2 + 64 * (4 + q), 64 * 2 + 2 * 8]
+    return {"fwd": fwd, "dx": dx, "dw": dw}[kind][grp]
+
+
 PEAK_TFLOPS = {"bf16x3": 2500.0, "f32": 157.3}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 
 
@@ -171,26 +186,56 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = S * B * world / (dt / args.steps)
-        # dominant kernel = the kernel SYMBOL (group_fwd / group_dx / group_dw; one symbol serves
-        # all branch groups) with the largest summed duration inside the timed region.  Its
-        # algorithmic FLOPs per launch = (sum over its launches of 2*MAC*contractions*S*B) / launches,
-        # so achieved = total algorithmic FLOPs / total time = FLOPs-per-launch / average duration.
+        # dominant kernel = the kernel SYMBOL with the largest summed duration inside the timed
+        # region.  One symbol may serve several branch groups; its algorithmic FLOPs per launch =
+        # (sum over its launches of 2*MAC*contractions*S*B) / launches, so
+        # achieved = total algorithmic FLOPs / total time = FLOPs-per-launch / average duration.
         ncontr = 2 if wl["fit_context"] in ("lrt", "flipout") else 1
+        em = {"lrt": 1, "flipout": 2}.get(wl["fit_context"], 0)
         macs = GROUP_MACS[wl["net"]]
+
+        def symbol(kind, grp):
+            """(profile tag) -> kernel symbol as rocprofv3 prints it (csrc/plan.hip dispatch)."""
+            if args.prec == "f32":
+                return {"fwd": f"group_fwd_kernel<PrecF32, {em}>", "dx": f"group_dx_kernel<PrecF32, {em}>",
+                        "dw": f"group_dw_kernel<PrecF32, {em}, 2>"}[kind]
+            conv = wl["net"] == "inception" and grp <= 2
+            if kind == "fwd":
+                return f"conv_fwd_dma_kernel<{em}>" if conv else (
+                    f"dense_fwd_dma_kernel<{em}>" if wl["net"] == "inception" else f"group_fwd_kernel<PrecBF, {em}>")
+            if kind == "dx":
+                return f"conv_dx_dma_kernel<{em}>" if conv else (
+                    f"dense_dx_bf_kernel<{em}>" if wl["net"] == "inception" else f"group_dx_kernel<PrecBF, {em}>")
+            if conv:
+                return f"conv_dw_bf_kernel<{em}, {[6, 11, 4][grp]}, 2, 3>"
+            return f"group_dw_kernel<PrecBF, {em}, 4>"
+
         agg = {}
         for (kind, grp), (tot_ms, cnt) in prof.items():
             if kind not in ("fwd", "dx", "dw"):
                 continue
-            a = agg.setdefault(kind, [0.0, 0, 0.0])
+            a = agg.setdefault(symbol(kind, grp), [0.0, 0, 0.0, 0.0])
             a[0] += tot_ms
             a[1] += cnt
             a[2] += 2.0 * macs[grp] * ncontr * S * B * args.steps  # dx[1] runs as 2 launches (direct + pooled)
-        kind, (tot_ms, cnt, flops_tot) = max(agg.items(), key=lambda kv: kv[1][0])
+            gb = group_bytes(wl["net"], kind, grp, em, S)
+            a[3] += (gb or 0.0) * S * B * args.steps
+        sym, (tot_ms, cnt, flops_tot, bytes_tot) = max(agg.items(), key=lambda kv: kv[1][0])
         flops_launch = flops_tot / cnt
         avg_s = tot_ms / cnt * 1e-3
         achieved = flops_launch / avg_s / 1e12
         peak = PEAK_TFLOPS[args.prec]
-        sym = {"fwd": "group_fwd_kernel", "dx": "group_dx_kernel", "dw": "group_dw_kernel"}[kind]
+        # HBM bytes per launch of that symbol from the committed PMC passes (profiles/, same workload):
+        # (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 read correction of MI355X_MICROARCH.md applied
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_final_flipout_conv_s10_pmc_summary.csv")
+        if args.workload == "flipout_conv_s10" and args.prec == "bf16x3" and not args.batch and os.path.exists(pmc):
+            import csv
+            for r in csv.DictReader(open(pmc)):
+                if sym.split("<")[0] in r["kernel"] and sym.split("<")[1].rstrip(">") in r["kernel"]:
+                    traffic = (2 * float(r["FETCH_SIZE_KB_per_launch"]) + float(r["WRITE_SIZE_KB_per_launch"])) * 1024
+                    break
+        bytes_launch = bytes_tot / cnt
         kernels = {f"{k[0]}[{k[1]}]": round(v[0] / args.steps, 4) for k, v in sorted(prof.items())}
         out = {
             "metric": "ELBO-step MC-samples x windows/sec, Conv BNN on N-CMAPSS",
@@ -201,9 +246,12 @@ def main():
                        "mc_samples": S, "windows_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "loss": loss},
             "roofline": {"bound": "mfma", "kernel": sym, "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_us": avg_s * 1e6, "flops_per_launch": flops_launch,
                          "launches_per_step": cnt / args.steps},
+            "roofline_hbm": {"bound": "hbm", "kernel": sym, "achieved": bytes_launch / avg_s / 1e9, "peak": 8000.0,
+                             "unit": "GB/s", "frac": bytes_launch / avg_s / 1e9 / 8000.0,
+                             "algorithmic_bytes_per_launch": bytes_launch, "traffic": traffic},
             "kernel_ms_per_step": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
