@@ -2279,3 +2279,171 @@ __global__ __launch_bounds__(DW_THREADS) void conv_dw_dma_kernel(const GroupArgs
     }
   }
 }
+
+// ==========================================================================================
+// dense_dw_bf_kernel : dW of a dense layer.  One workgroup = (particle, 128-channel chunk of the
+// input, split of the particle's 32-row windows); its 32 (x2) dW tiles stay in registers while the
+// windows stream through LDS (register-prefetched one window ahead).  Flipout signs are per
+// example row here, so the sign-multiplied copies (X*s_in, dz*s_out) are explicit images.
+// ==========================================================================================
+template <int EM>
+__global__ __launch_bounds__(512) void dense_dw_bf_kernel(const GroupArgs A, int nchunk, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool DUAL = (EM != EM_PLAIN);
+  constexpr bool LRT = (EM == EM_LRT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GroupDesc& G = A.g;
+  const BranchDesc& br = G.br[0];
+  const LayerDesc& ly = A.layers[br.layer];
+  int bid = blockIdx.x;
+  const int split = bid % nsplit; bid /= nsplit;
+  const int chunk = bid % nchunk;
+  const int s = bid / nchunk;
+  const int c0 = chunk * DN_CH;
+  const int cw = min(DN_CH, br.cin_p - c0);          // multiple of 16
+  const int zw = (br.cout + 15) & ~15;               // <= 64
+  constexpr int RSX = DN_CH + 8, RSZ = 64 + 8;
+  u16* xi = (u16*)smem;
+  u16* x2 = xi + DN_ROWS * RSX;
+  u16* dz = x2 + DN_ROWS * RSX;
+  u16* dz2 = dz + DN_ROWS * RSZ;
+  const TensorRef tin = A.t[G.in_t], tg = A.t[br.out_t + T_GRAD], ty = A.t[br.out_t], tq = A.t[br.q_t];
+  const u16* g_x = (const u16*)tin.p;
+  const int pp = A.cg.per_particle, B = A.cg.B;
+  // staging plan: X unit = thread (row = tid >> 4, c8 = tid & 15); dz unit = thread < 256 (row = tid >> 3, c8 = tid & 7)
+  const int xr = tid >> 4, xc8 = tid & 15;
+  const bool x_on = xc8 * 8 < cw;
+  const int zr = tid >> 3, zc8 = tid & 7;
+  const bool z_on = tid < 256 && zc8 * 8 < br.cout;
+  uint4 px = make_uint4(0, 0, 0, 0), pz = make_uint4(0, 0, 0, 0), py = make_uint4(0, 0, 0, 0), pq = make_uint4(0, 0, 0, 0);
+  uint32_t psi = 0, pso = 0;
+  int p_nvalid = 0;
+  auto prefetch = [&](int wl) {
+    const int row0 = s * B + wl * DN_ROWS;
+    const int nvalid = min(DN_ROWS, B - wl * DN_ROWS);
+    p_nvalid = nvalid;
+    px = pz = py = pq = make_uint4(0, 0, 0, 0);
+    psi = pso = 0;
+    if (x_on && xr < nvalid) {
+      px = *(const uint4*)(g_x + (long)(row0 + xr) * tin.ctot + br.in_off + c0 + xc8 * 8);
+      if constexpr (EM == EM_FLIPOUT) {
+        const int bit0 = c0 + xc8 * 8;
+        psi = A.nz.sign_in[ly.sign_in_off * A.nz.examples + (long)(row0 + xr) * ly.sign_in_words + (bit0 >> 5)] >> (bit0 & 31);
+      }
+    }
+    if (z_on && zr < nvalid) {
+      const long o = (long)(row0 + zr) * tg.ctot + br.out_off + zc8 * 8;
+      pz = *(const uint4*)((const u16*)tg.p + o);
+      if (br.relu) py = *(const uint4*)((const u16*)ty.p + o);
+      if constexpr (LRT) pq = *(const uint4*)((const u16*)tq.p + o);
+      if constexpr (EM == EM_FLIPOUT) {
+        const int bit0 = br.n_off + zc8 * 8;
+        pso = A.nz.sign_out[ly.sign_out_off * A.nz.examples + (long)(row0 + zr) * ly.sign_out_words + (bit0 >> 5)] >> (bit0 & 31);
+      }
+    }
+  };
+  // tiles: t = wave + 8 m, (nt, ct) = (t / 8, t % 8)
+  f32x4 acc_a[4], acc_b[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    acc_a[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc_b[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float gb_a = 0.f, gb_b = 0.f;
+  const int ntl = zw >> 4, ctl = (cw + 15) >> 4;
+  auto sgn8 = [](uint4 v, uint32_t bits) {   // flip the sign of bf16 element e where bit e is set
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] ^= (((bits >> (2 * e)) & 1u) << 15) | (((bits >> (2 * e + 1)) & 1u) << 31);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  auto mul8 = [](uint4 a, uint4 b) {
+    const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float l = bf2f((u16)(x[e] & 0xffff)) * bf2f((u16)(y[e] & 0xffff));
+      const float h = bf2f((u16)(x[e] >> 16)) * bf2f((u16)(y[e] >> 16));
+      o[e] = (uint32_t)f2bf(l) | ((uint32_t)f2bf(h) << 16);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
+  int wl = split;
+  if (wl < pp) prefetch(wl);
+  const int gq = lane >> 4, qq = (lane >> 2) & 3, pq4 = lane & 3;
+  for (; wl < pp; wl += nsplit) {
+    __syncthreads();
+    // ---- images of this window ----
+    {
+      *(uint4*)&xi[xr * RSX + xc8 * 8] = px;
+      if constexpr (LRT) *(uint4*)&x2[xr * RSX + xc8 * 8] = mul8(px, px);
+      if constexpr (EM == EM_FLIPOUT) *(uint4*)&x2[xr * RSX + xc8 * 8] = sgn8(px, psi);
+      if (tid < 256) {
+        uint4 g = pz;
+        if (br.relu) {
+          auto msk = [](uint32_t yy) {
+            const uint32_t lo = ((yy & 0x8000u) == 0 && (yy & 0x7fffu) != 0) ? 0xffffu : 0u;
+            const uint32_t hi = ((yy & 0x80000000u) == 0 && (yy & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+            return lo | hi;
+          };
+          g.x &= msk(py.x); g.y &= msk(py.y); g.z &= msk(py.z); g.w &= msk(py.w);
+        }
+        *(uint4*)&dz[zr * RSZ + zc8 * 8] = g;
+        if constexpr (LRT) *(uint4*)&dz2[zr * RSZ + zc8 * 8] = mul8(g, pq);
+        if constexpr (EM == EM_FLIPOUT) *(uint4*)&dz2[zr * RSZ + zc8 * 8] = sgn8(g, pso);
+      }
+    }
+    __syncthreads();
+    if (wl + nsplit < pp) prefetch(wl + nsplit);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int t = wave + 8 * m;
+      const int nt = t >> 3, ct = t & 7;
+      if (nt < ntl && ct < ctl) {
+        const int r0 = 8 * gq + qq;
+        const u16* a0 = &dz[r0 * RSZ + nt * 16 + 4 * pq4];
+        const u16* b0 = &xi[r0 * RSX + ct * 16 + 4 * pq4];
+        acc_a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(a0, a0 + 4 * RSZ), tr_frag(b0, b0 + 4 * RSX), acc_a[m], 0, 0, 0);
+        if constexpr (DUAL) {
+          const u16* a2 = &dz2[r0 * RSZ + nt * 16 + 4 * pq4];
+          const u16* b2 = &x2[r0 * RSX + ct * 16 + 4 * pq4];
+          acc_b[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(a2, a2 + 4 * RSZ), tr_frag(b2, b2 + 4 * RSX), acc_b[m], 0, 0, 0);
+        }
+      }
+    }
+    if (chunk == 0 && tid < br.cout) {
+      float sa = 0.f, sb = 0.f;
+      for (int r = 0; r < DN_ROWS; ++r) {
+        sa += bf2f(dz[r * RSZ + tid]);
+        // bias gradients: LRT needs sum(dz*q); Flipout's bias gradient arrives through slot A only
+        if constexpr (LRT) sb += bf2f(dz2[r * RSZ + tid]);
+      }
+      gb_a += sa;
+      gb_b += sb;
+    }
+  }
+  float* gwa = A.gw_a + A.gw_stride * s + ly.w_off;
+  float* gwb = A.gw_b + A.gw_stride * s + ly.w_off;
+  const int i4 = 4 * (lane >> 4), jc = lane & 15;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int t = wave + 8 * m;
+    const int nt = t >> 3, ct = t & 7;
+    if (nt >= ntl || ct >= ctl) continue;
+    const int c = c0 + ct * 16 + jc;
+    if (c >= br.cin_p) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nt * 16 + i4 + r;
+      if (n >= br.cout) continue;
+      const long o = (long)(br.n_off + n) * ly.KP + c;
+      atomicAdd(gwa + o, acc_a[m][r]);
+      if constexpr (DUAL) atomicAdd(gwb + o, acc_b[m][r]);
+    }
+  }
+  if (chunk == 0 && tid < br.cout) {
+    atomicAdd(A.gb_a + (long)A.gb_stride * s + ly.bias_off + br.n_off + tid, gb_a);
+    if constexpr (LRT) atomicAdd(A.gb_b + (long)A.gb_stride * s + ly.bias_off + br.n_off + tid, gb_b);
+  }
+}

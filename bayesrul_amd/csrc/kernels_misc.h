@@ -84,6 +84,36 @@ __global__ void gen_signs_kernel(uint32_t* dst, int words, int S, int B, int Bgl
     if (q * 4 + r < words) dst[ex * words + q * 4 + r] = v[r];
 }
 
+// all layers' sign arrays in one launch: blockIdx.y = entry (layer x {in, out})
+struct SignGenArgs {
+  int n;
+  int S, B, Bglob, goff;
+  uint64_t seed;
+  uint32_t step;
+  uint32_t* dst[2 * BNN_MAX_LAYERS];
+  int words[2 * BNN_MAX_LAYERS];
+  int layer[2 * BNN_MAX_LAYERS];
+  uint32_t kind[2 * BNN_MAX_LAYERS];
+};
+__global__ void gen_signs_all_kernel(const SignGenArgs A) {
+  const int e = blockIdx.y;
+  const int words = A.words[e];
+  const int w4 = (words + 3) >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)A.S * A.B * w4) return;
+  const int q = (int)(idx % w4);
+  const long ex = idx / w4;
+  const int s = (int)(ex / A.B), b = (int)(ex - (long)s * A.B);
+  const uint32_t gex = (uint32_t)(A.goff + b);
+  const uint4 u = philox4x32_10(gex * (uint32_t)w4 + (uint32_t)q, (uint32_t)s, A.kind[e] | ((uint32_t)A.layer[e] << 8),
+                                A.step, (uint32_t)A.seed, (uint32_t)(A.seed >> 32));
+  const uint32_t v[4] = {u.x, u.y, u.z, u.w};
+  uint32_t* dst = A.dst[e];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (q * 4 + r < words) dst[ex * words + q * 4 + r] = v[r];
+}
+
 // floats (+1/-1) [rows][C] -> packed bits (1 = negative)
 __global__ void pack_signs_kernel(const float* src, uint32_t* dst, long rows, int C, int words) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

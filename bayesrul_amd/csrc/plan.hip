@@ -597,6 +597,10 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
   c->nz.sign_out = so;
   if (c->mode == BNN_MODE_FLIPOUT) {
     const long ex = (long)S * B;
+    SignGenArgs SG{};
+    SG.S = S; SG.B = B; SG.Bglob = a->global_batch; SG.goff = a->global_batch_offset;
+    SG.seed = seed; SG.step = step;
+    int maxw4 = 1;
     for (int i = 0; i < p->n_layers; ++i) {
       const LayerDesc& l = p->layers[i];
       uint32_t* di = si + l.sign_in_off * ex;
@@ -605,16 +609,22 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
         const long n = ex * l.sign_in_words;
         pack_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(nz->sign_in[i], di, ex, l.cin_img, l.sign_in_words);
       } else {
-        const long n = ex * ((l.sign_in_words + 3) / 4);
-        gen_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(di, l.sign_in_words, S, B, a->global_batch, a->global_batch_offset, i, NK_SIGN_IN, seed, step);
+        SG.dst[SG.n] = di; SG.words[SG.n] = l.sign_in_words; SG.layer[SG.n] = i; SG.kind[SG.n] = NK_SIGN_IN;
+        maxw4 = std::max(maxw4, (l.sign_in_words + 3) / 4);
+        SG.n++;
       }
       if (nz && nz->sign_out && nz->sign_out[i]) {
         const long n = ex * l.sign_out_words;
         pack_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(nz->sign_out[i], d_o, ex, l.cout, l.sign_out_words);
       } else {
-        const long n = ex * ((l.sign_out_words + 3) / 4);
-        gen_signs_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(d_o, l.sign_out_words, S, B, a->global_batch, a->global_batch_offset, i, NK_SIGN_OUT, seed, step);
+        SG.dst[SG.n] = d_o; SG.words[SG.n] = l.sign_out_words; SG.layer[SG.n] = i; SG.kind[SG.n] = NK_SIGN_OUT;
+        maxw4 = std::max(maxw4, (l.sign_out_words + 3) / 4);
+        SG.n++;
       }
+    }
+    if (SG.n > 0) {
+      const long n = ex * maxw4;
+      gen_signs_all_kernel<<<dim3((unsigned)((n + 255) / 256), SG.n), dim3(256), 0, c->st>>>(SG);
     }
   }
   c->nz.use_philox_lrt = 1;
@@ -1135,6 +1145,22 @@ static int launch_conv_dw_dma(const GroupArgs& A0, const LayerDesc* layers, int 
   return 0;
 }
 
+static int launch_dense_dw_bf(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  const BranchDesc& br = A.g.br[0];
+  const int nchunk = (br.cin_p + DN_CH - 1) / DN_CH;
+  int nsplit = std::max(1, 384 / std::max(1, A.cg.S * nchunk));
+  nsplit = std::min(nsplit, A.cg.per_particle);
+  const int lds = (2 * DN_ROWS * (DN_CH + 8) + 2 * DN_ROWS * (64 + 8)) * 2;
+  const unsigned grid = (unsigned)(A.cg.S * nchunk * nsplit);
+  ProfScope ps_(pf, PK_DW, gi, st);
+  if (em == EM_PLAIN) dense_dw_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
+  else if (em == EM_LRT) dense_dw_bf_kernel<EM_LRT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
+  else dense_dw_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int launch_conv_dx_dma(const GroupArgs& A0, const LayerDesc* layers, int em, int pool_sel, hipStream_t st, Prof* pf,
                               int gi) {
   GroupArgs A = A0;
@@ -1297,10 +1323,15 @@ static int do_head(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, float* preds,
 
 static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   const size_t gwb = (size_t)c->S * p->img_total * 4, gbb = (size_t)c->S * p->bias_total * 4;
-  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gw_a), 0, gwb, c->st));
-  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gw_b), 0, gwb, c->st));
-  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gb_a), 0, gbb, c->st));
-  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gb_b), 0, gbb, c->st));
+  if (c->S == p->d.max_particles) {
+    // gw_a | gw_b | gb_a | gb_b are back to back in the workspace: one fill
+    HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gw_a), 0, (p->o_gb_b - p->o_gw_a) + gbb, c->st));
+  } else {
+    HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gw_a), 0, gwb, c->st));
+    HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gw_b), 0, gwb, c->st));
+    HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gb_a), 0, gbb, c->st));
+    HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gb_b), 0, gbb, c->st));
+  }
   for (int gi = p->n_groups - 1; gi >= 0; --gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
@@ -1308,6 +1339,10 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
     else if (!A.g.is_dense)
       BNN_TRY((getenv("BNN_DW_DMA") ? launch_conv_dw_dma : launch_conv_dw_bf)(A, p->layers, c->em, c->st, &p->prof, gi));
+    else if (A.g.n_branch == 1 && !A.g.in_bcast && A.g.br[0].cout <= 64 && (A.g.br[0].cout % 8) == 0 &&
+             (A.g.br[0].cin_p % 16) == 0 && A.g.br[0].cin_real == A.g.br[0].cin_p && A.t[A.g.in_t].fmt == TF_BF16 &&
+             (A.t[A.g.in_t].ctot % 8) == 0 && (A.t[A.g.br[0].out_t].ctot % 8) == 0 && A.t[A.g.br[0].out_t].fmt == TF_BF16)
+      BNN_TRY(launch_dense_dw_bf(A, c->em, c->st, &p->prof, gi));
     else
       BNN_TRY((launch_dw<PrecBF, 4>(A, c->em, c->st, &p->prof, gi)));
     bool any_direct = false, any_pool = false;
