@@ -2447,3 +2447,313 @@ __global__ __launch_bounds__(512) void dense_dw_bf_kernel(const GroupArgs A, int
     if constexpr (LRT) atomicAdd(A.gb_b + (long)A.gb_stride * s + ly.bias_off + br.n_off + tid, gb_b);
   }
 }
+
+// ==========================================================================================
+// conv_dw_mw_kernel : dW of a conv group, NWI windows per iteration.
+// The per-iteration costs (3 workgroup barriers, the exposed part of the global-load latency)
+// are amortised over NWI windows; all loads of an iteration are issued back to back (16-byte
+// units straight from the bf16 planes), so the memory pipe sees NWI windows of traffic at once.
+// Tiles (all branches of the group) stay in registers across the windows of the workgroup.
+// ==========================================================================================
+template <int EM, int MAXT, int NWI>
+__global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs A, const ConvDwPlan D) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool DUAL = (EM != EM_PLAIN);
+  constexpr bool LRT = (EM == EM_LRT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const GroupDesc& G = A.g;
+  const int s = blockIdx.x / D.nsplit, split = blockIdx.x - s * D.nsplit;
+  const int L = G.L, B = A.cg.B;
+  const int cwp = G.in_cin_p;
+  const int xw16 = (cwp + 15) & ~15;
+  const int RSx = img_row_stride(xw16, true), RSz = img_row_stride(D.zw, true);
+  const int xbytes = (IMG_ROWS * RSx * 2 + 15) & ~15, zbytes = (IMG_ROWS * RSz * 2 + 15) & ~15;
+  // per window: x_hi | [xp] | dz | [x_sq | xp_sq | dz2]
+  const int o_xp = xbytes;
+  const int o_dz = o_xp + (D.has_pool ? xbytes : 0);
+  const int o_xsq = o_dz + zbytes;
+  const int o_xpsq = o_xsq + (LRT ? xbytes : 0);
+  const int o_dz2 = o_xpsq + ((LRT && D.has_pool) ? xbytes : 0);
+  const int o_sg = o_dz2 + (LRT ? zbytes : 0);              // flipout sign words [branch][8]
+  const int wbytes = o_sg + ((EM == EM_FLIPOUT) ? 128 : 0);
+  {
+    const int total = (NWI * wbytes) >> 2;
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < total; k += CV_THREADS) z[k] = 0u;
+  }
+  const TensorRef tin = A.t[G.in_t];
+  const int x8 = cwp >> 3, z8 = D.zw >> 3;
+  const int xunits = L * x8, zunits = L * z8;
+
+  // ---- per-thread staging plan: <= 1 X unit and <= 2 dz units per window (16 bytes each) ----
+  const bool x_on = tid < xunits;
+  const int x_row = tid / x8, x_c = (tid - x_row * x8) * 8;
+  const int x_src = x_row * tin.ctot + x_c, x_dst = (x_row + HALO) * RSx + x_c;
+  int z_src[2], z_dst[2], z_ct[2];
+  const u16 *z_g[2], *z_y[2], *z_q[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int unit = tid + u * CV_THREADS;
+    z_src[u] = z_dst[u] = z_ct[u] = 0;
+    z_g[u] = z_y[u] = z_q[u] = nullptr;
+    if (unit < zunits) {
+      const int row = unit / z8, zc = (unit - row * z8) * 8;
+      int b = 0;
+      for (int k = 1; k < G.n_branch; ++k)
+        if (zc >= D.zoff[k]) b = k;
+      const BranchDesc& br = G.br[b];
+      const int c = zc - D.zoff[b];
+      if (c < br.cout) {   // 8-channel units: the tensors' channel pads are zero and in bounds
+        const TensorRef tg = A.t[br.out_t + T_GRAD];
+        z_ct[u] = tg.ctot;
+        z_src[u] = row * tg.ctot + br.out_off + c;
+        z_dst[u] = (row + HALO) * RSz + zc;
+        z_g[u] = (const u16*)tg.p;
+        z_y[u] = br.relu ? (const u16*)A.t[br.out_t].p : nullptr;
+        z_q[u] = LRT ? (const u16*)A.t[br.q_t].p : nullptr;
+      }
+    }
+  }
+  // ---- tiles ----
+  f32x4 acc_a[MAXT], acc_b[MAXT];
+  int t_a[MAXT], t_b[MAXT], t_so[MAXT], t_si[MAXT];   // t_so / t_si: LDS sign word index | bit of lane 0 << 8
+  bool t_ok[MAXT];
+#pragma unroll
+  for (int m = 0; m < MAXT; ++m) {
+    acc_a[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc_b[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int t = wave + CV_WAVES * m;
+    t_ok[m] = t < D.ntiles;
+    t_a[m] = t_b[m] = t_so[m] = t_si[m] = 0;
+    if (t_ok[m]) {
+      const DwTile T = D.tile[t];
+      const BranchDesc& br = G.br[T.b];
+      const LayerDesc& ly = A.layers[br.layer];
+      const int n0 = D.zoff[T.b] + T.nt * 16;
+      const int c0 = br.in_off + T.ct * 16;
+      const int tshift = T.tap - ly.pad;
+      const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+      const int r0 = 8 * g + q;
+      t_a[m] = (o_dz >> 1) + (r0 + HALO) * RSz + n0 + 4 * p;
+      t_b[m] = (br.pool ? (o_xp >> 1) : 0) + (r0 + tshift + HALO) * RSx + c0 + 4 * p;
+      const int nbit = br.n_off + T.nt * 16, cbit = T.ct * 16;
+      t_so[m] = (T.b * 8 + 4 + (nbit >> 5)) | ((nbit & 31) << 8);
+      t_si[m] = (T.b * 8 + (cbit >> 5)) | ((cbit & 31) << 8);
+    }
+  }
+  // bias gradients: column sums of dz through one MFMA against an all-ones B fragment; wave w owns
+  // the 16-channel blocks w, w+8 of the concatenated dz image
+  f32x4 acc_ba[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc_bb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int nzt = D.zw >> 4;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  // flipout sign words of a window: thread tid < 8 * n_branch fetches word (branch, k)
+  const uint32_t* sg_src = nullptr;
+  long sg_stride = 0;
+  if (EM == EM_FLIPOUT && tid < 8 * G.n_branch) {
+    const int b = tid >> 3, k = tid & 7;
+    const LayerDesc& ly = A.layers[G.br[b].layer];
+    if (k < 4 && k < ly.sign_in_words) {
+      sg_src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + k;
+      sg_stride = ly.sign_in_words;
+    } else if (k >= 4 && k < 6 && k - 4 < ly.sign_out_words) {
+      sg_src = A.nz.sign_out + ly.sign_out_off * A.nz.examples + (k - 4);
+      sg_stride = ly.sign_out_words;
+    }
+  }
+  const int pp = B;
+  const int my_nwin = (pp - split + D.nsplit - 1) / D.nsplit;
+  const u16* g_x = (const u16*)tin.p;
+  auto msk = [](uint32_t yy) {   // bf16 > 0
+    const uint32_t lo = ((yy & 0x8000u) == 0 && (yy & 0x7fffu) != 0) ? 0xffffu : 0u;
+    const uint32_t hi = ((yy & 0x80000000u) == 0 && (yy & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+    return lo | hi;
+  };
+  auto sq8 = [](uint4 a) {
+    const uint32_t x[4] = {a.x, a.y, a.z, a.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float l = bf2f((u16)(x[e] & 0xffff)), h = bf2f((u16)(x[e] >> 16));
+      o[e] = (uint32_t)f2bf(l * l) | ((uint32_t)f2bf(h * h) << 16);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
+  auto mul8 = [](uint4 a, uint4 b) {
+    const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float l = bf2f((u16)(x[e] & 0xffff)) * bf2f((u16)(y[e] & 0xffff));
+      const float h = bf2f((u16)(x[e] >> 16)) * bf2f((u16)(y[e] >> 16));
+      o[e] = (uint32_t)f2bf(l) | ((uint32_t)f2bf(h) << 16);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
+  auto max8 = [](uint4 a, uint4 b) {
+    const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float l = fmaxf(bf2f((u16)(x[e] & 0xffff)), bf2f((u16)(y[e] & 0xffff)));
+      const float h = fmaxf(bf2f((u16)(x[e] >> 16)), bf2f((u16)(y[e] >> 16)));
+      o[e] = (uint32_t)f2bf(l) | ((uint32_t)f2bf(h) << 16);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  };
+
+  for (int k0 = 0; k0 < my_nwin; k0 += NWI) {
+    const int nw = min(NWI, my_nwin - k0);
+    // ---- issue every load of the iteration, then consume ----
+    uint4 px[NWI], pz[NWI][2], py[NWI][2], pq[NWI][2];
+    uint32_t psg[NWI];
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      px[i] = make_uint4(0, 0, 0, 0);
+      psg[i] = 0u;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) pz[i][u] = py[i][u] = pq[i][u] = make_uint4(0, 0, 0, 0);
+      if (i < nw && !(A.pool_sel & 8)) {
+        const int wl = split + (k0 + i) * D.nsplit;
+        const long w = (long)s * B + wl;
+        const long xrow0 = (G.in_bcast ? wl : w) * L;
+        if (x_on) px[i] = *(const uint4*)(g_x + xrow0 * tin.ctot + x_src);
+        if (sg_src) psg[i] = sg_src[w * sg_stride];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (z_g[u]) {
+            const long o = w * L * z_ct[u] + z_src[u];
+            pz[i][u] = *(const uint4*)(z_g[u] + o);
+            if (z_y[u]) py[i][u] = *(const uint4*)(z_y[u] + o);
+            if constexpr (LRT) pq[i][u] = *(const uint4*)(z_q[u] + o);
+          }
+      }
+    }
+    __syncthreads();   // previous iteration's images consumed
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      u16* base = (u16*)(smem + i * wbytes);
+      if (x_on) {
+        *(uint4*)&base[x_dst] = px[i];
+        if constexpr (LRT) *(uint4*)&base[(o_xsq >> 1) + x_dst] = sq8(px[i]);
+      }
+      if constexpr (EM == EM_FLIPOUT) {
+        if (tid < 32) ((uint32_t*)((char*)base + o_sg))[tid] = psg[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (z_g[u]) {
+          uint4 g = pz[i][u];
+          if (z_y[u]) {
+            g.x &= msk(py[i][u].x); g.y &= msk(py[i][u].y); g.z &= msk(py[i][u].z); g.w &= msk(py[i][u].w);
+          }
+          *(uint4*)&base[(o_dz >> 1) + z_dst[u]] = g;
+          if constexpr (LRT) *(uint4*)&base[(o_dz2 >> 1) + z_dst[u]] = mul8(g, pq[i][u]);
+        }
+    }
+    __syncthreads();
+    if (D.has_pool && !(A.pool_sel & 2)) {
+#pragma unroll
+      for (int i = 0; i < NWI; ++i) {
+        u16* base = (u16*)(smem + i * wbytes);
+        if (x_on) {
+          uint4 m = *(const uint4*)&base[x_dst];
+          if (x_row > 0) m = max8(m, *(const uint4*)&base[x_dst - RSx]);
+          if (x_row + 1 < L) m = max8(m, *(const uint4*)&base[x_dst + RSx]);
+          *(uint4*)&base[(o_xp >> 1) + x_dst] = m;
+          if constexpr (LRT) *(uint4*)&base[(o_xpsq >> 1) + x_dst] = sq8(m);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- tiles ----
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      if (i < nw) {
+        const u16* base = (const u16*)(smem + i * wbytes);
+        const uint32_t* sg = (const uint32_t*)((const char*)base + o_sg);
+#pragma unroll
+        for (int m = 0; m < MAXT; ++m) {
+          if (t_ok[m] && !(A.pool_sel & 1)) {
+            const u16* a0 = base + t_a[m];
+            const u16* b0 = base + t_b[m];
+            const bf16x8 fa = tr_frag(a0, a0 + 4 * RSz);
+            const bf16x8 fb = tr_frag(b0, b0 + 4 * RSx);
+            acc_a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc_a[m], 0, 0, 0);
+            if constexpr (LRT) {
+              const u16* a2 = a0 + ((o_dz2 - o_dz) >> 1);
+              const u16* b2 = b0 + ((o_xsq) >> 1);   // x_sq follows x_hi, xp_sq follows xp at the same distance
+              acc_b[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(a2, a2 + 4 * RSz), tr_frag(b2, b2 + 4 * RSx),
+                                                                 acc_b[m], 0, 0, 0);
+            } else if constexpr (EM == EM_FLIPOUT) {
+              const bool no = (sg[t_so[m] & 0xff] >> ((t_so[m] >> 8) + (lane & 15))) & 1u;
+              const bool ni = (sg[t_si[m] & 0xff] >> ((t_si[m] >> 8) + (lane & 15))) & 1u;
+              acc_b[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xor_sign(fa, no), xor_sign(fb, ni), acc_b[m], 0, 0, 0);
+            }
+          }
+        }
+        if (!(A.pool_sel & 4)) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int zt = wave + CV_WAVES * q;
+            if (zt < nzt) {
+              const int g = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
+              const u16* a0 = base + (o_dz >> 1) + (8 * g + qq + HALO) * RSz + zt * 16 + 4 * p;
+              acc_ba[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(a0, a0 + 4 * RSz), ones, acc_ba[q], 0, 0, 0);
+              if constexpr (LRT) {
+                const u16* a2 = a0 + ((o_dz2 - o_dz) >> 1);
+                acc_bb[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(a2, a2 + 4 * RSz), ones, acc_bb[q], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- write out ----
+  const int i4 = 4 * (lane >> 4), jc = lane & 15;
+#pragma unroll
+  for (int m = 0; m < MAXT; ++m) {
+    const int t = wave + CV_WAVES * m;
+    if (t >= D.ntiles) continue;
+    const DwTile T = D.tile[t];
+    const BranchDesc& br = G.br[T.b];
+    const LayerDesc& ly = A.layers[br.layer];
+    const int c = T.ct * 16 + jc;
+    if (c >= br.cin_p) continue;
+    float* gwa = A.gw_a + A.gw_stride * s + ly.w_off;
+    float* gwb = A.gw_b + A.gw_stride * s + ly.w_off;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = T.nt * 16 + i4 + r;
+      if (n >= br.cout) continue;
+      const long o = (long)(br.n_off + n) * ly.KP + (long)T.tap * ly.cin_img + c;
+      atomicAdd(gwa + o, acc_a[m][r]);
+      if constexpr (DUAL) atomicAdd(gwb + o, acc_b[m][r]);
+    }
+  }
+  if ((lane & 15) == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int zt = wave + CV_WAVES * q;
+      if (zt >= nzt) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int zc = zt * 16 + 4 * (lane >> 4) + r;
+        int b = 0;
+        for (int k = 1; k < G.n_branch; ++k)
+          if (zc >= D.zoff[k]) b = k;
+        const BranchDesc& br = G.br[b];
+        const int n = zc - D.zoff[b];
+        if (n < br.cout) {
+          const LayerDesc& ly = A.layers[br.layer];
+          atomicAdd(A.gb_a + (long)A.gb_stride * s + ly.bias_off + br.n_off + n, acc_ba[q][r]);
+          if constexpr (LRT) atomicAdd(A.gb_b + (long)A.gb_stride * s + ly.bias_off + br.n_off + n, acc_bb[q][r]);
+        }
+      }
+    }
+  }
+}

@@ -1057,6 +1057,56 @@ static int launch_conv_dw_bf(const GroupArgs& A0, const LayerDesc* layers, int e
   return launch_conv_dw_bf_em<EM_FLIPOUT>(A, D, lds, grid, st);
 }
 
+template <int EM, int NWI>
+static int launch_conv_dw_mw_em(const GroupArgs& A, const ConvDwPlan& D, int lds, unsigned grid, hipStream_t st) {
+  const int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
+  if (tpw <= 4) {
+    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 4, NWI>, lds));
+    conv_dw_mw_kernel<EM, 4, NWI><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+  } else if (tpw <= 6) {
+    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 6, NWI>, lds));
+    conv_dw_mw_kernel<EM, 6, NWI><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+  } else {
+    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 11, NWI>, lds));
+    conv_dw_mw_kernel<EM, 11, NWI><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  ConvDwPlan D;
+  build_conv_dw_plan(A, layers, &D);
+  if (const char* dbg = getenv("BNN_DW_ABLATE")) A.pool_sel = atoi(dbg);  // timing experiments only
+  if (D.ntiles > 96 || (D.ntiles + CV_WAVES - 1) / CV_WAVES > 11) return fail(BNN_E_INVALID, "conv dW plan too large");
+  if (A.g.in_cin_p % 8 || D.zw % 8) return fail(BNN_E_INVALID, "conv dW: channel counts must be multiples of 8");
+  if (A.g.L * (A.g.in_cin_p / 8) > CV_THREADS || A.g.L * (D.zw / 8) > 2 * CV_THREADS)
+    return fail(BNN_E_INVALID, "conv dW staging plan exceeds the compiled unit counts");
+  D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+  const int xw16 = rup(A.g.in_cin_p, 16);
+  const int xbytes = (IMG_ROWS * img_row_stride(xw16, true) * 2 + 15) & ~15;
+  const int zbytes = (IMG_ROWS * img_row_stride(D.zw, true) * 2 + 15) & ~15;
+  const bool lrt = em == EM_LRT;
+  const int wbytes = xbytes + (D.has_pool ? xbytes : 0) + zbytes + (lrt ? xbytes + (D.has_pool ? xbytes : 0) + zbytes : 0);
+  // windows per iteration: bounded by LDS and by the registers that hold an iteration's loads
+  // (variants that would spill are avoided: measured with -Rpass-analysis)
+  const int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
+  int nwi = lrt ? (tpw > 6 ? 1 : 2) : (tpw > 6 ? 2 : (em == EM_FLIPOUT && tpw <= 4 ? 2 : 4));
+  while (nwi > 1 && nwi * wbytes > 160 * 1024) nwi /= 2;
+  if (nwi * wbytes > 160 * 1024) return fail(BNN_E_INVALID, "conv dW: %d bytes of LDS per window", wbytes);
+  const int lds = nwi * wbytes;
+  const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
+  ProfScope ps_(pf, PK_DW, gi, st);
+#define DISPATCH_NWI(EMV)                                                            \
+  (nwi == 4 ? launch_conv_dw_mw_em<EMV, 4>(A, D, lds, grid, st)                      \
+            : (nwi == 2 ? launch_conv_dw_mw_em<EMV, 2>(A, D, lds, grid, st) : launch_conv_dw_mw_em<EMV, 1>(A, D, lds, grid, st)))
+  if (em == EM_PLAIN) return DISPATCH_NWI(EM_PLAIN);
+  if (em == EM_LRT) return DISPATCH_NWI(EM_LRT);
+  return DISPATCH_NWI(EM_FLIPOUT);
+#undef DISPATCH_NWI
+}
+
 static int launch_conv_dw_dma(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   static thread_local ConvDw2Plan D;   // large; copied into the kernel arguments at launch
@@ -1338,7 +1388,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
     else if (!A.g.is_dense)
-      BNN_TRY((getenv("BNN_DW_DMA") ? launch_conv_dw_dma : launch_conv_dw_bf)(A, p->layers, c->em, c->st, &p->prof, gi));
+      BNN_TRY((getenv("BNN_DW_DMA") ? launch_conv_dw_dma : (getenv("BNN_DW_V1") ? launch_conv_dw_bf : launch_conv_dw_mw))(A, p->layers, c->em, c->st, &p->prof, gi));
     else if (A.g.n_branch == 1 && !A.g.in_bcast && A.g.br[0].cout <= 64 && (A.g.br[0].cout % 8) == 0 &&
              (A.g.br[0].cin_p % 16) == 0 && A.g.br[0].cin_real == A.g.br[0].cin_p && A.t[A.g.in_t].fmt == TF_BF16 &&
              (A.t[A.g.in_t].ctot % 8) == 0 && (A.t[A.g.br[0].out_t].ctot % 8) == 0 && A.t[A.g.br[0].out_t].fmt == TF_BF16)
