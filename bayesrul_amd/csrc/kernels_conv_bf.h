@@ -793,13 +793,38 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+#define BNN_WAIT_VMCNT(N)                                                     \
+  do {                                                                        \
+    switch (N) {                                                              \
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;         \
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;         \
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;         \
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;         \
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;         \
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;         \
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;         \
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;         \
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;         \
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;         \
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;       \
+      case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;       \
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;       \
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;        \
+    }                                                                         \
+  } while (0)
+
+// The branches of a group may be dealt to FW_KINDS workgroup kinds (two 8-wave workgroups per CU
+// instead of one 16-wave workgroup: their barrier / DMA stalls overlap).
+enum { FW_KINDS = 2 };
 struct ConvFwd2Plan {
-  int nsplit, has_pool, n_red_groups, pad_;
-  FwdJob job[FW_NC];
+  int nsplit, nkinds, pad0_, pad1_;
+  int has_pool[FW_KINDS], n_red_groups[FW_KINDS];
+  FwdJob job[FW_KINDS][FW_NC];
 };
 
-template <int EM>
-__global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArgs A, const ConvFwd2Plan F) {
+template <int EM, int NC, int NL>
+__global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const GroupArgs A, const ConvFwd2Plan F) {
+  constexpr int NTHR = (NC + NL) * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool DUAL = (EM != EM_PLAIN);
   constexpr bool LRT = (EM == EM_LRT);
@@ -807,7 +832,10 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const GroupDesc& G = A.g;
-  const int s = blockIdx.x / F.nsplit, split = blockIdx.x - s * F.nsplit;
+  const int kind = blockIdx.x % F.nkinds;
+  const int bid = blockIdx.x / F.nkinds;
+  const int s = bid / F.nsplit, split = bid - s * F.nsplit;
+  const int has_pool = F.has_pool[kind], n_red_groups = F.n_red_groups[kind];
   const int L = G.L, B = A.cg.B;
   const int cwp = G.in_cin_p, c8n = cwp >> 3;
   const int swm = (c8n - 1) & 15;           // swizzle mask (c8n is a power of two: 4 or 16)
@@ -821,13 +849,13 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
   {
     const int total = ((FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4) >> 2;
     uint32_t* z = (uint32_t*)smem;
-    for (int k = tid; k < total; k += FW_THREADS) z[k] = 0u;
+    for (int k = tid; k < total; k += NTHR) z[k] = 0u;
   }
   const TensorRef tin = A.t[G.in_t];
   const int nchunk = L * c8n;                       // 16-byte chunks per plane per window
   const int ninst = (nchunk + 63) >> 6;             // DMA instructions per plane
-  const bool is_loader = wave >= FW_NC;
-  const int lw = wave - FW_NC;
+  const bool is_loader = wave >= NC;
+  const int lw = wave - NC;
   const int pp = B;
   const int nwin = (pp - split + F.nsplit - 1) / F.nsplit;   // windows of this workgroup
   auto win_of = [&](int k) { return split + k * F.nsplit; };
@@ -835,7 +863,7 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
   // =========================== loader state ===========================
   // DMA instructions of a window: 2 planes x ninst, dealt round-robin to the 4 loader waves;
   // addresses are recomputed per issue (no per-thread arrays: they would land in scratch)
-  const int my_ninst = is_loader ? max(0, (2 * ninst - lw + FW_NL - 1) / FW_NL) : 0;
+  const int my_ninst = is_loader ? max(0, (2 * ninst - lw + NL - 1) / NL) : 0;
   // flipout sign words of a window: [branch][8] = 4 words sign_in + 2 words sign_out, by loader 0
   const uint32_t* sg_src = nullptr;
   long sg_stride = 0;
@@ -862,7 +890,7 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
     asm volatile("" : "+v"(lane_o));
 #define BNN_DMA_ONE(I)                                                                              \
     {                                                                                               \
-      const int inst = lw + (I) * FW_NL;                                                            \
+      const int inst = lw + (I) * NL;                                                            \
       if (inst < 2 * ninst) {                                                                       \
         const int plane = inst >= ninst ? 1 : 0;                                                    \
         const int q0 = (inst - plane * ninst) * 64;                                                 \
@@ -878,6 +906,12 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
     BNN_DMA_ONE(1)
     BNN_DMA_ONE(2)
     BNN_DMA_ONE(3)
+    if (NL < 4) {
+      BNN_DMA_ONE(4)
+      BNN_DMA_ONE(5)
+      BNN_DMA_ONE(6)
+      BNN_DMA_ONE(7)
+    }
 #undef BNN_DMA_ONE
     if (EM == EM_FLIPOUT && lw == 0) {
       if (sg_ok) dma4(sg_src + ((long)s * B + wl) * sg_stride, __builtin_amdgcn_readfirstlane(lds_addr(sgn + (k % FW_SLOTS) * 64)));
@@ -899,7 +933,7 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
     k_pk[ks] = HALO;
   }
   if (!is_loader) {
-    J = F.job[wave];
+    J = F.job[kind][wave];
     if (J.b >= 0) {
       const BranchDesc& br = G.br[J.b];
       const LayerDesc& ly = A.layers[br.layer];
@@ -961,26 +995,14 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
     if (is_loader) {
       const bool more = (k + 1 < nwin);
       // my_ninst (+1 sign DMA for loader 0) instructions per window may stay in flight
-      if (!more) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else if (EM == EM_FLIPOUT && lw == 0) {
-        if (my_ninst == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if (my_ninst == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (my_ninst == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (my_ninst == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      } else {
-        if (my_ninst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (my_ninst == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (my_ninst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (my_ninst == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      const int nfly = my_ninst + ((EM == EM_FLIPOUT && lw == 0) ? 1 : 0);
+      if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else BNN_WAIT_VMCNT(nfly);
     }
     lds_barrier();                                // B1: raw planes of window k visible; compute(k-1) finished
     // ---- derived planes (all 16 waves) ----
-    if ((F.has_pool || LRT) && !(A.pool_sel & 2)) {
-      for (int U = tid; U < nchunk; U += FW_THREADS) {
+    if ((has_pool || LRT) && !(A.pool_sel & 2)) {
+      for (int U = tid; U < nchunk; U += NTHR) {
         const int row = U / c8n, p = U - row * c8n;
         const int ri = row + HALO;
         const int c8 = p ^ (ri & swm);
@@ -989,7 +1011,7 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
         const uint32_t hh[4] = {h0.x, h0.y, h0.z, h0.w}, ll[4] = {l0.x, l0.y, l0.z, l0.w};
         uint32_t ha[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0}, hb[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0};
         const bool up = row > 0, dn = row + 1 < L;
-        if (F.has_pool) {
+        if (has_pool) {
           if (up) {
             const int o2 = (ri - 1) * RS + ((c8 ^ ((ri - 1) & swm)) * 8);
             const uint4 a = *(const uint4*)&r_hi[o2], b = *(const uint4*)&r_lo[o2];
@@ -1012,7 +1034,7 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
             const int sh = 16 * e;
             const u16 h = (u16)(hh[q] >> sh), l = (u16)(ll[q] >> sh);
             u16 bh_ = h, bl_ = l;
-            if (F.has_pool) {
+            if (has_pool) {
               float best = bf2f(h) + bf2f(l);
               if (up) {
                 const u16 h2 = (u16)(ha[q] >> sh), l2 = (u16)(la[q] >> sh);
@@ -1035,13 +1057,13 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
           }
           ph[q] = oh; pl[q] = ol; sq[q] = os; psq[q] = ops;
         }
-        if (F.has_pool) {
+        if (has_pool) {
           *(uint4*)&der[o] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
           *(uint4*)&der[(pbytes >> 1) + o] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
         }
         if constexpr (LRT) {
           *(uint4*)&der[pbytes + o] = make_uint4(sq[0], sq[1], sq[2], sq[3]);
-          if (F.has_pool) *(uint4*)&der[pbytes + (pbytes >> 1) + o] = make_uint4(psq[0], psq[1], psq[2], psq[3]);
+          if (has_pool) *(uint4*)&der[pbytes + (pbytes >> 1) + o] = make_uint4(psq[0], psq[1], psq[2], psq[3]);
         }
       }
       lds_barrier();                              // B2: derived planes visible
@@ -1096,7 +1118,7 @@ __global__ __launch_bounds__(FW_THREADS) void conv_fwd_dma_kernel(const GroupArg
       }
     }
     // ---------------- K-split reduction ----------------
-    if (F.n_red_groups > 0) {
+    if (n_red_groups > 0) {
       if (!is_loader && J.b >= 0 && J.grp >= 0 && !J.owner) {
         float* r = red + (size_t)wave * (2 * 2 * 256);
 #pragma unroll
@@ -1222,25 +1244,6 @@ struct ConvDxPlan {
   DxInst inst[DX_MAXI];
 };
 
-#define BNN_WAIT_VMCNT(N)                                                     \
-  do {                                                                        \
-    switch (N) {                                                              \
-      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;         \
-      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;         \
-      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;         \
-      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;         \
-      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;         \
-      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;         \
-      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;         \
-      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;         \
-      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;         \
-      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;         \
-      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;       \
-      case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;       \
-      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;       \
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;        \
-    }                                                                         \
-  } while (0)
 
 // chunk position of channel chunk c8 in image row r of a dense image with cb8 chunks per row
 __device__ __forceinline__ int swz(int c8, int r, int cb8) {

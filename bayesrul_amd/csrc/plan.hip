@@ -887,17 +887,20 @@ static int build_conv_fwd_plan(const GroupArgs& A, const LayerDesc* layers, Conv
 }
 
 // jobs of the role-specialised forward (one per compute wave): tiles whose K exceeds FW_KS k-steps
-// are split, then the longest jobs keep being split until all FW_NC compute waves have work.
-static int build_conv_fwd2_plan(const GroupArgs& A, const LayerDesc* layers, ConvFwd2Plan* F) {
-  *F = ConvFwd2Plan{};
-  for (int w = 0; w < FW_NC; ++w) F->job[w].b = -1;
+// are split, then the longest jobs keep being split until all `nc` compute waves have work.
+// `mask` selects the branches of this workgroup kind.
+static int build_conv_fwd2_jobs(const GroupArgs& A, const LayerDesc* layers, unsigned mask, int nc, FwdJob* job,
+                                int* has_pool, int* n_red) {
+  for (int w = 0; w < FW_NC; ++w) job[w].b = -1;
+  *has_pool = 0;
   struct Tile { int b, nt, ks, nm; };
   std::vector<Tile> tiles;
   int njobs = 0;
   for (int b = 0; b < A.g.n_branch; ++b) {
+    if (!(mask & (1u << b))) continue;
     const BranchDesc& br = A.g.br[b];
     const LayerDesc& ly = layers[br.layer];
-    if (br.pool) F->has_pool = 1;
+    if (br.pool) *has_pool = 1;
     const int ks = (ly.taps * (br.cin_p / 8) + 3) / 4;
     for (int n = 0; n < br.ntiles; ++n) {
       const int nm = (ks + FW_KS - 1) / FW_KS;
@@ -905,10 +908,10 @@ static int build_conv_fwd2_plan(const GroupArgs& A, const LayerDesc* layers, Con
       njobs += nm;
     }
   }
-  if (njobs > FW_NC) return fail(BNN_E_INVALID, "conv fwd plan: %d jobs exceed %d compute waves", njobs, FW_NC);
-  while (njobs < FW_NC) {
+  if (njobs > nc) return 1;   // does not fit: caller falls back
+  while (njobs < nc) {
     int best = -1;
-    double bv = 1.0;  // only split jobs with more than one k-step per member
+    double bv = 1.0;
     for (size_t t = 0; t < tiles.size(); ++t) {
       const double v = (double)tiles[t].ks / tiles[t].nm;
       if (v > bv && tiles[t].nm < tiles[t].ks) { bv = v; best = (int)t; }
@@ -920,7 +923,7 @@ static int build_conv_fwd2_plan(const GroupArgs& A, const LayerDesc* layers, Con
   int w = 0, ngrp = 0;
   for (size_t t = 0; t < tiles.size(); ++t) {
     for (int m = 0; m < tiles[t].nm; ++m, ++w) {
-      FwdJob& J = F->job[w];
+      FwdJob& J = job[w];
       J.b = (signed char)tiles[t].b;
       J.nt = (signed char)tiles[t].nt;
       J.ks0 = (signed char)(tiles[t].ks * m / tiles[t].nm);
@@ -929,39 +932,76 @@ static int build_conv_fwd2_plan(const GroupArgs& A, const LayerDesc* layers, Con
       J.owner = m == 0;
       J.member = (signed char)m;
       J.nmember = (signed char)tiles[t].nm;
-      if (J.ks1 - J.ks0 > FW_KS) return fail(BNN_E_INVALID, "conv fwd plan: job with more than %d k-steps", FW_KS);
+      if (J.ks1 - J.ks0 > FW_KS) return 1;
     }
     if (tiles[t].nm > 1) ngrp++;
   }
-  F->n_red_groups = ngrp;
+  *n_red = ngrp;
+  return 0;
+}
+
+template <int NC, int NL>
+static int launch_conv_fwd_dma_t(const GroupArgs& A, const ConvFwd2Plan& F, int em, int lds, unsigned grid, hipStream_t st) {
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_PLAIN, NC, NL>, lds));
+    conv_fwd_dma_kernel<EM_PLAIN, NC, NL><<<dim3(grid), dim3((NC + NL) * 64), lds, st>>>(A, F);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_LRT, NC, NL>, lds));
+    conv_fwd_dma_kernel<EM_LRT, NC, NL><<<dim3(grid), dim3((NC + NL) * 64), lds, st>>>(A, F);
+  } else {
+    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_FLIPOUT, NC, NL>, lds));
+    conv_fwd_dma_kernel<EM_FLIPOUT, NC, NL><<<dim3(grid), dim3((NC + NL) * 64), lds, st>>>(A, F);
+  }
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
 static int launch_conv_fwd_dma(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
-  ConvFwd2Plan F;
-  BNN_TRY(build_conv_fwd2_plan(A, layers, &F));
+  ConvFwd2Plan F{};
   if (const char* dbg = getenv("BNN_FWD_ABLATE")) A.pool_sel = atoi(dbg);  // timing experiments only (wrong results)
   const int c8n = A.g.in_cin_p / 8;
   if (c8n != 4 && c8n != 16) return fail(BNN_E_INVALID, "conv fwd: input of %d channels (need 32 or 128)", A.g.in_cin_p);
-  if ((A.g.L * c8n + 63) / 64 * 2 > 4 * FW_NL) return fail(BNN_E_INVALID, "conv fwd: window too large for the loader plan");
-  F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+  if ((A.g.L * c8n + 63) / 64 * 2 > 16) return fail(BNN_E_INVALID, "conv fwd: window too large for the loader plan");
   const int pbytes = IMG_ROWS * A.g.in_cin_p * 2;
-  const int lds = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + (F.n_red_groups > 0 ? FW_NC * 4 * 256 * 4 : 0);
+  // preferred: two workgroup kinds of 8 waves (6 compute + 2 loaders), two workgroups per CU
+  bool two = A.g.n_branch > 1 && !getenv("BNN_FWD_ONEKIND");
+  if (two) {
+    // deal the branches: heaviest (k-steps x n-tiles) first onto the lighter kind
+    int wgt[BNN_MAX_BRANCH], order[BNN_MAX_BRANCH], load[2] = {0, 0};
+    unsigned mask[2] = {0, 0};
+    for (int b = 0; b < A.g.n_branch; ++b) {
+      const BranchDesc& br = A.g.br[b];
+      wgt[b] = br.ntiles * ((layers[br.layer].taps * (br.cin_p / 8) + 3) / 4);
+      order[b] = b;
+    }
+    std::sort(order, order + A.g.n_branch, [&](int x, int y) { return wgt[x] > wgt[y]; });
+    for (int i = 0; i < A.g.n_branch; ++i) {
+      const int k = load[1] < load[0] ? 1 : 0;
+      mask[k] |= 1u << order[i];
+      load[k] += wgt[order[i]];
+    }
+    F.nkinds = 2;
+    for (int k = 0; k < 2 && two; ++k)
+      if (build_conv_fwd2_jobs(A, layers, mask[k], 6, F.job[k], &F.has_pool[k], &F.n_red_groups[k])) two = false;
+    const int lds2 = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + ((F.n_red_groups[0] | F.n_red_groups[1]) ? 6 * 4 * 256 * 4 : 0);
+    if (two && lds2 > 80 * 1024) two = false;   // two workgroups must fit one CU
+    if (two) {
+      F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+      const unsigned grid = (unsigned)(2 * A.cg.S * F.nsplit);
+      ProfScope ps_(pf, PK_FWD, gi, st);
+      return launch_conv_fwd_dma_t<6, 2>(A, F, em, lds2, grid, st);
+    }
+  }
+  F = ConvFwd2Plan{};
+  F.nkinds = 1;
+  if (build_conv_fwd2_jobs(A, layers, 0xffu, FW_NC, F.job[0], &F.has_pool[0], &F.n_red_groups[0]))
+    return fail(BNN_E_INVALID, "conv fwd plan: jobs exceed %d compute waves", FW_NC);
+  F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+  const int lds = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + (F.n_red_groups[0] > 0 ? FW_NC * 4 * 256 * 4 : 0);
   const unsigned grid = (unsigned)(A.cg.S * F.nsplit);
   ProfScope ps_(pf, PK_FWD, gi, st);
-  if (em == EM_PLAIN) {
-    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_PLAIN>, lds));
-    conv_fwd_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
-  } else if (em == EM_LRT) {
-    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_LRT>, lds));
-    conv_fwd_dma_kernel<EM_LRT><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
-  } else {
-    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_FLIPOUT>, lds));
-    conv_fwd_dma_kernel<EM_FLIPOUT><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
+  return launch_conv_fwd_dma_t<FW_NC, FW_NL>(A, F, em, lds, grid, st);
 }
 
 static int launch_conv_fwd_bf(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
