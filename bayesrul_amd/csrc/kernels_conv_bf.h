@@ -786,6 +786,39 @@ __device__ __forceinline__ void dma4(const void* gsrc, uint32_t lds_dst) {
                : "v"(gsrc), "s"(lds_dst)
                : "memory");
 }
+// two floats -> packed bf16 pair (one v_cvt_pk_bf16_f32)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// hi / lo bf16 planes of 4 floats: hi = bf16(v), lo = bf16(v - hi)
+__device__ __forceinline__ void split4(f32x4 v, uint2& hi, uint2& lo) {
+  const uint32_t h01 = cvt_pk(v[0], v[1]), h23 = cvt_pk(v[2], v[3]);
+  const float r0 = v[0] - __uint_as_float(h01 << 16), r1 = v[1] - __uint_as_float(h01 & 0xffff0000u);
+  const float r2 = v[2] - __uint_as_float(h23 << 16), r3 = v[3] - __uint_as_float(h23 & 0xffff0000u);
+  hi = make_uint2(h01, h23);
+  lo = make_uint2(cvt_pk(r0, r1), cvt_pk(r2, r3));
+}
+// 256-entry table: sign byte (8 channels) -> XOR mask of a bf16x8 fragment (one ds_read_b128)
+__device__ __forceinline__ void build_sign_lut(uint4* lut, int tid, int nthreads) {
+  for (int b = tid; b < 256; b += nthreads) {
+    uint32_t m[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = (((b >> (2 * q)) & 1u) << 15) | (((b >> (2 * q + 1)) & 1u) << 31);
+    lut[b] = make_uint4(m[0], m[1], m[2], m[3]);
+  }
+}
+
+// diagnostics only (GroupArgs::dbg, null in production): lane 0 of every wave of workgroup 0 records
+// s_memtime at phase `ph` of window iteration `k`
+#define BNN_STAMP_DECL(A)                                                                                   \
+  const bool stamp_on = (A).dbg != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;                   \
+  const int stamp_wave = threadIdx.x >> 6;                                                                  \
+  auto stamp = [&](int k, int ph) {                                                                         \
+    if (stamp_on && k < 48) (A).dbg[((size_t)stamp_wave * 48 + k) * 8 + ph] = __builtin_amdgcn_s_memtime(); \
+  }
+
 // workgroup barrier that only waits for this wave's LDS traffic (never for VMEM)
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -845,7 +878,8 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
   u16* raw = (u16*)smem;
   u16* der = (u16*)(smem + FW_SLOTS * 2 * pbytes);
   uint32_t* sgn = (uint32_t*)(smem + (FW_SLOTS * 2 + 4) * pbytes);   // [FW_SLOTS][64]
-  float* red = (float*)(smem + (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4);
+  uint4* lut = (uint4*)(smem + (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4);   // 4 KB sign-mask table
+  float* red = (float*)(smem + (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + 4096);
   {
     const int total = ((FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4) >> 2;
     uint32_t* z = (uint32_t*)smem;
@@ -921,7 +955,8 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
   // =========================== compute state ===========================
   const int i16 = lane & 15, g4 = lane >> 4;
   bf16x8 w_hi[KS], w_lo[KS], w_b[KS];
-  int k_pk[KS];   // packed: image row base (tap - pad + HALO) | global channel chunk << 8 | chunk inside the layer << 16
+  int k_o[KS][2];  // LDS element offset of this lane's B fragment (m-tile 0 / 1): window invariant
+  int k_sb[KS];    // flipout: sign word index | bit shift << 8 of the lane's 8 channels
   FwdJob J = FwdJob{-1, 0, 0, 0, -1, 0, 0, 0};
   int j_nks = 0, j_pool = 0;
   f32x4 e_ba = {0.f, 0.f, 0.f, 0.f}, e_bb = {0.f, 0.f, 0.f, 0.f};
@@ -930,7 +965,8 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     w_hi[ks] = w_lo[ks] = w_b[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    k_pk[ks] = HALO;
+    k_o[ks][0] = k_o[ks][1] = HALO * RS;
+    k_sb[ks] = 0;
   }
   if (!is_loader) {
     J = F.job[kind][wave];
@@ -951,7 +987,17 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
           w_hi[ks] = *(const bf16x8*)((const u16*)A.ws.a_hi + sa + ly.w_off + wo);
           w_lo[ks] = *(const bf16x8*)((const u16*)A.ws.a_lo + sa + ly.w_off + wo);
           if constexpr (DUAL) w_b[ks] = *(const bf16x8*)((const u16*)A.ws.b + sb + ly.w_off + wo);
-          k_pk[ks] = valid ? ((tap - ly.pad + HALO) | (((br.in_off >> 3) + c8) << 8) | (c8 << 16)) : HALO;
+          {
+            const int rb = valid ? (tap - ly.pad + HALO) : HALO;
+            const int cg = valid ? ((br.in_off >> 3) + c8) : 0;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const int rr = rb + mt * 16 + i16;
+              k_o[ks][mt] = rr * RS + ((cg ^ (rr & swm)) * 8);
+            }
+            const int cl = valid ? c8 : 0;
+            k_sb[ks] = (cl >> 2) | (((cl & 3) * 8) << 8);
+          }
         }
       }
       const int chb = J.nt * 16 + 4 * g4;
@@ -980,6 +1026,7 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
   }
 
   // =========================== prologue ===========================
+  if (EM == EM_FLIPOUT) build_sign_lut(lut, tid, NTHR);
   __syncthreads();  // zero fill visible
   if (is_loader) {
     if (nwin > 0) issue(0);
@@ -987,7 +1034,9 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
   }
 
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  BNN_STAMP_DECL(A);
   for (int k = 0; k < nwin; ++k) {
+    stamp(k, 0);
     const int slot = k % FW_SLOTS;
     u16* r_hi = raw + slot * pbytes;             // 2 planes per slot: elements = 2*pbytes/2
     u16* r_lo = r_hi + (pbytes >> 1);
@@ -999,10 +1048,14 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
       if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else BNN_WAIT_VMCNT(nfly);
     }
+    stamp(k, 1);
     lds_barrier();                                // B1: raw planes of window k visible; compute(k-1) finished
+    stamp(k, 2);
     // ---- derived planes (all 16 waves) ----
     if ((has_pool || LRT) && !(A.pool_sel & 2)) {
-      for (int U = tid; U < nchunk; U += NTHR) {
+      // compute waves only: the loaders' vmcnt must count nothing but their own DMAs (the arg-max store)
+      if (!is_loader)
+      for (int U = tid; U < nchunk; U += NC * 64) {
         const int row = U / c8n, p = U - row * c8n;
         const int ri = row + HALO;
         const int c8 = p ^ (ri & swm);
@@ -1026,6 +1079,7 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
           }
         }
         uint32_t ph[4], pl[4], sq[4], psq[4];
+        uint32_t am[2] = {0u, 0u};   // arg-max code of each of the 8 channels: 0 = row-1, 1 = row, 2 = row+1
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           uint32_t oh = 0, ol = 0, os = 0, ops = 0;
@@ -1035,17 +1089,20 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
             const u16 h = (u16)(hh[q] >> sh), l = (u16)(ll[q] >> sh);
             u16 bh_ = h, bl_ = l;
             if (has_pool) {
+              // torch scans row-1, row, row+1 and keeps the FIRST maximum
               float best = bf2f(h) + bf2f(l);
+              uint32_t code = 1u;
               if (up) {
                 const u16 h2 = (u16)(ha[q] >> sh), l2 = (u16)(la[q] >> sh);
                 const float v = bf2f(h2) + bf2f(l2);
-                if (v > best) { best = v; bh_ = h2; bl_ = l2; }
+                if (v >= best) { best = v; bh_ = h2; bl_ = l2; code = 0u; }
               }
               if (dn) {
                 const u16 h2 = (u16)(hb[q] >> sh), l2 = (u16)(lb[q] >> sh);
                 const float v = bf2f(h2) + bf2f(l2);
-                if (v > best) { best = v; bh_ = h2; bl_ = l2; }
+                if (v > best) { best = v; bh_ = h2; bl_ = l2; code = 2u; }
               }
+              am[q >> 1] |= code << (8 * (2 * (q & 1) + e));
             }
             oh |= (uint32_t)bh_ << sh;
             ol |= (uint32_t)bl_ << sh;
@@ -1060,13 +1117,19 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
         if (has_pool) {
           *(uint4*)&der[o] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
           *(uint4*)&der[(pbytes >> 1) + o] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          if (A.amax) {
+            const long R = (long)(s * B + win_of(k)) * L + row;
+            *(uint2*)(A.amax + R * cwp + c8 * 8) = make_uint2(am[0], am[1]);
+          }
         }
         if constexpr (LRT) {
           *(uint4*)&der[pbytes + o] = make_uint4(sq[0], sq[1], sq[2], sq[3]);
           if (has_pool) *(uint4*)&der[pbytes + (pbytes >> 1) + o] = make_uint4(psq[0], psq[1], psq[2], psq[3]);
         }
       }
+      stamp(k, 3);
       lds_barrier();                              // B2: derived planes visible
+      stamp(k, 4);
     }
     if (is_loader) {
       if (k + 2 < nwin) issue(k + 2);             // slot (k+2)%3 == (k-1)%3: free since B1
@@ -1090,16 +1153,12 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
         if (ks < j_nks) {
           u32x4 fm = {0u, 0u, 0u, 0u};
           if constexpr (EM == EM_FLIPOUT) {
-            const int c8 = (k_pk[ks] >> 16) & 0xff;
-            const uint32_t byte = (sg[c8 >> 2] >> ((c8 & 3) * 8)) & 0xffu;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              fm[q] = (((byte >> (2 * q)) & 1u) << 15) | (((byte >> (2 * q + 1)) & 1u) << 31);
+            const uint32_t byte = (sg[k_sb[ks] & 0xff] >> (k_sb[ks] >> 8)) & 0xffu;
+            fm = __builtin_bit_cast(u32x4, lut[byte]);
           }
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
-            const int rr = (k_pk[ks] & 0xff) + mt * 16 + i16;
-            const int o = rr * RS + ((((k_pk[ks] >> 8) & 0xff) ^ (rr & swm)) * 8);
+            const int o = k_o[ks][mt];
             const bf16x8 bh = *(const bf16x8*)&x_hi[o];
             const bf16x8 bl = *(const bf16x8*)&x_lo[o];
             acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bh, acc_a[mt], 0, 0, 0);
@@ -1117,6 +1176,7 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
         }
       }
     }
+    stamp(k, 5);
     // ---------------- K-split reduction ----------------
     if (n_red_groups > 0) {
       if (!is_loader && J.b >= 0 && J.grp >= 0 && !J.owner) {
@@ -1145,6 +1205,7 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
         }
       }
     }
+    stamp(k, 6);
     // ---------------- epilogue ----------------
     if (!is_loader && J.b >= 0 && e_nv > 0 && (J.grp < 0 || J.owner) && !(A.pool_sel & 1)) {
       const int w = s * B + win_of(k);
@@ -1192,27 +1253,16 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
         const long oo = (long)R * e_octot + e_ooff;
-        u16 h[4], l[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h[r] = f2bf(v[r]);
-          l[r] = f2bf(v[r] - bf2f(h[r]));
-        }
-        if (e_nv >= 4) {
-          *(uint2*)(e_ohi + oo) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-          *(uint2*)(e_olo + oo) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
-          if constexpr (LRT) *(uint2*)(e_q + oo) = pack_bf4(qv);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < e_nv) {
-              e_ohi[oo + r] = h[r];
-              e_olo[oo + r] = l[r];
-              if constexpr (LRT) e_q[oo + r] = f2bf(qv[r]);
-            }
-        }
+        // channels beyond cout inside the 4-group are channel pads of the output tensor (zero
+        // weights and bias -> exact zeros), so the whole group is always stored
+        uint2 hv, lv;
+        split4(v, hv, lv);
+        *(uint2*)(e_ohi + oo) = hv;
+        *(uint2*)(e_olo + oo) = lv;
+        if constexpr (LRT) *(uint2*)(e_q + oo) = make_uint2(cvt_pk(qv[0], qv[1]), cvt_pk(qv[2], qv[3]));
       }
     }
+    stamp(k, 7);
   }
 }
 
@@ -1427,7 +1477,9 @@ __global__ __launch_bounds__(DX_THREADS) void conv_dx_dma_kernel(const GroupArgs
   }
 
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  BNN_STAMP_DECL(A);
   for (int k = 0; k < nwin; ++k) {
+    stamp(k, 0);
     const int slotk = k % FW_SLOTS;
     const u16* r_dy = (const u16*)(smem + slotk * slot_bytes);
     const u16* r_y = r_dy + (zbytes >> 1);
@@ -1437,7 +1489,9 @@ __global__ __launch_bounds__(DX_THREADS) void conv_dx_dma_kernel(const GroupArgs
       if (k + 1 < nwin) BNN_WAIT_VMCNT(n_issue);
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    stamp(k, 1);
     lds_barrier();   // B1
+    stamp(k, 2);
     // ---- dz = dY * [Y > 0] (, dz2 = dz * q) ----
     if (m_o >= 0) {
       uint4 g = *(const uint4*)&r_dy[m_o];
@@ -1464,9 +1518,12 @@ __global__ __launch_bounds__(DX_THREADS) void conv_dx_dma_kernel(const GroupArgs
         *(uint4*)&dz2[m_o] = make_uint4(out[0], out[1], out[2], out[3]);
       }
     }
+    stamp(k, 3);
     lds_barrier();   // B2
+    stamp(k, 4);
     if (is_loader) {
       if (k + 2 < nwin) issue(k + 2);
+      stamp(k, 5);
     }
     // ---------------- MFMA ----------------
     if (has_job) {
@@ -1510,6 +1567,7 @@ __global__ __launch_bounds__(DX_THREADS) void conv_dx_dma_kernel(const GroupArgs
           }
         }
       }
+      stamp(k, 5);
       // ---------------- epilogue ----------------
       const int wl = win_of(k);
       const long w = (long)s * B + wl;
@@ -1553,6 +1611,7 @@ __global__ __launch_bounds__(DX_THREADS) void conv_dx_dma_kernel(const GroupArgs
         *(uint2*)((u16*)tdx.p + (w * L + row) * tdx.ctot + och) = pack_bf4(v);
       }
     }
+    stamp(k, 6);
   }
 }
 
@@ -2608,8 +2667,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs 
     return make_uint4(o[0], o[1], o[2], o[3]);
   };
 
+  BNN_STAMP_DECL(A);
   for (int k0 = 0; k0 < my_nwin; k0 += NWI) {
     const int nw = min(NWI, my_nwin - k0);
+    const int kst = k0 / NWI;
+    stamp(kst, 0);
     // ---- issue every load of the iteration, then consume ----
     uint4 px[NWI], pz[NWI][2], py[NWI][2], pq[NWI][2];
     uint32_t psg[NWI];
@@ -2635,7 +2697,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs 
           }
       }
     }
+    stamp(kst, 1);
     __syncthreads();   // previous iteration's images consumed
+    stamp(kst, 2);
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
       u16* base = (u16*)(smem + i * wbytes);
@@ -2657,7 +2721,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs 
           if constexpr (LRT) *(uint4*)&base[(o_dz2 >> 1) + z_dst[u]] = mul8(g, pq[i][u]);
         }
     }
+    stamp(kst, 3);
     __syncthreads();
+    stamp(kst, 4);
     if (D.has_pool && !(A.pool_sel & 2)) {
 #pragma unroll
       for (int i = 0; i < NWI; ++i) {
@@ -2672,6 +2738,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs 
       }
       __syncthreads();
     }
+    stamp(kst, 5);
     // ---- tiles ----
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
@@ -2715,6 +2782,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs 
         }
       }
     }
+    stamp(kst, 6);
   }
   // ---- write out ----
   const int i4 = 4 * (lane >> 4), jc = lane & 15;

@@ -19,6 +19,10 @@ struct GroupArgs {
   int pool_sel;    // dx: 0 = branches reading the tensor directly, 1 = pooled branches
   int nsplit;      // dw: window splits per (job, particle)
   int lds_per_wave;  // bytes
+  unsigned char* amax;     // conv groups with a pooled branch: arg-max code (0 row-1, 1 row, 2 row+1) of
+                           // MaxPool1d(3,1,1) per element of the input tensor, [windows * L][in_cin_p]; written by the
+                           // forward, read by the fused dX
+  unsigned long long* dbg;  // diagnostics only: phase time stamps of workgroup 0 ([wave][48 windows][8 phases]); null = off
 };
 
 template <class P>

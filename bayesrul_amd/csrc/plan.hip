@@ -16,6 +16,7 @@
 #include "kernels_group.h"
 #include "kernels_misc.h"
 #include "kernels_conv_bf.h"
+#include "kernels_conv_dx.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -60,8 +61,12 @@ struct Prof {
   std::vector<hipEvent_t> ev;   // pairs
   std::vector<int> tag;         // kind * 16 + group
   size_t used = 0;
+  bool filter = false;          // record only the tags set in `sel`
+  bool sel[256] = {};
+  std::string names[256];       // kernel symbol (as rocprofv3 prints it, without the argument list) last launched under a tag
   hipEvent_t* next(int t) {
     if (!on) return nullptr;
+    if (filter && !(t >= 0 && t < 256 && sel[t])) return nullptr;
     if (used + 2 > ev.size()) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
@@ -76,10 +81,22 @@ struct Prof {
   }
 };
 struct ProfScope {
+  Prof* pf;
+  int tag;
   hipEvent_t* e;
   hipStream_t st;
-  ProfScope(Prof* p, int kind, int group, hipStream_t s) : e(p ? p->next(kind * 16 + group) : nullptr), st(s) {
+  ProfScope(Prof* p, int kind, int group, hipStream_t s)
+      : pf(p), tag(kind * 16 + group), e(p ? p->next(kind * 16 + group) : nullptr), st(s) {
     if (e) (void)hipEventRecord(e[0], st);
+  }
+  void name(const char* fmt, ...) {
+    if (!e || !pf) return;
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    pf->names[tag] = buf;
   }
   ~ProfScope() {
     if (e) (void)hipEventRecord(e[1], st);
@@ -87,9 +104,15 @@ struct ProfScope {
 };
 enum { PK_FWD = 0, PK_DX = 1, PK_DW = 2, PK_SAMPLE = 3, PK_HEAD = 4, PK_FINALIZE = 5, PK_ADAM = 6, PK_POOLBWD = 7, PK_NOISE = 8 };
 
+enum { DBG_STAMP_BYTES = 16 * 48 * 8 * 8 };
+struct BnnPlan;
+static unsigned long long* dbg_for(const BnnPlan* p, int kind, int gi);
+
 struct BnnPlan {
   BnnPlanDesc d;
   Prof prof;
+  unsigned long long* dbg_buf = nullptr;   // diagnostics only (bnn_debug_stamps): device stamp buffer
+  int dbg_tag = -1;                        // kind * 16 + group of the launch that records stamps
   int n_layers = 0, n_sites = 0, n_groups = 0;
   long P = 0;
   std::vector<std::string> site_names, layer_names;
@@ -106,7 +129,7 @@ struct BnnPlan {
   // workspace layout (byte offsets)
   size_t ws_bytes = 0;
   size_t o_layers, o_a_hi, o_a_lo, o_b, o_at, o_bt, o_bias_a, o_bias_b, o_gw_a, o_gw_b, o_gb_a, o_gb_b, o_eps, o_radr,
-      o_norms, o_sign_in, o_sign_out, o_acc, o_scal, o_preds, o_poolgrad, o_xplanes, o_tens;
+      o_norms, o_sign_in, o_sign_out, o_acc, o_scal, o_preds, o_poolgrad, o_xplanes, o_amax, o_tens;
   size_t elem = 4;
   bool bound = false;
   BnnBuffers bufs{};
@@ -358,6 +381,7 @@ static void layout_workspace(BnnPlan* p) {
   p->o_scal = take(64);
   p->o_preds = take((size_t)S * p->d.max_batch * 2 * 4);
   p->o_poolgrad = take((size_t)cap * p->d.win_length * 128 * 4);
+  p->o_amax = take(p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION ? (size_t)cap * p->d.win_length * 128 : 0);
   p->o_xplanes = take((size_t)2 * p->d.max_batch * p->d.win_length * 32 * 2);
   p->o_tens = o;
   // activations / grads / q.  f32 plans keep fp32 rows; bf16x3 plans keep bf16 planes
@@ -429,7 +453,10 @@ extern "C" int bnn_plan_create(const BnnPlanDesc* desc, BnnPlan** out) {
   *out = p;
   return 0;
 }
-extern "C" void bnn_plan_destroy(BnnPlan* plan) { delete plan; }
+extern "C" void bnn_plan_destroy(BnnPlan* plan) {
+  if (plan && plan->dbg_buf) (void)hipFree(plan->dbg_buf);
+  delete plan;
+}
 extern "C" int bnn_plan_num_params(const BnnPlan* p, int64_t* P) {
   if (!p || !P) return fail(BNN_E_INVALID, "null argument");
   *P = p->P;
@@ -724,6 +751,10 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
     A->t[T_X] = TensorRef{xp, xp + (size_t)p->d.max_batch * p->d.win_length * 32 * 2, 32, TF_BF16};
   }
   A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), nullptr, 128, p->d.prec == BNN_PREC_BF16X3 ? TF_BF16 : TF_F32};
+  A->amax = nullptr;
+  if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION)
+    for (int b = 0; b < A->g.n_branch; ++b)
+      if (A->g.br[b].pool && A->g.br[b].dx_t >= 0) A->amax = (unsigned char*)w + p->o_amax;
   A->layers = (const LayerDesc*)(w + p->o_layers);
   A->gw_a = ws_f(p, p->o_gw_a);
   A->gw_b = ws_f(p, p->o_gw_b);
@@ -733,12 +764,17 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
   A->gb_stride = p->bias_total;
 }
 
+static unsigned long long* dbg_for(const BnnPlan* p, int kind, int gi) {
+  return (p->dbg_buf && p->dbg_tag == kind * 16 + gi) ? p->dbg_buf : nullptr;
+}
+
 static int img_bytes(int ch, bool bf) { return (IMG_ROWS * img_row_stride(ch, bf) * (bf ? 2 : 4) + 15) & ~15; }
 
 template <class P>
 static int launch_fwd(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   ProfScope ps_(pf, PK_FWD, gi, st);
+  ps_.name("group_fwd_kernel<%s, %d>", P::BF ? "PrecBF" : "PrecF32", em);
   const int nimg = P::BF ? 3 : 2;
   A.lds_per_wave = nimg * img_bytes(DENSE_CHUNK, P::BF);
   const int lds = 4 * A.lds_per_wave;
@@ -761,6 +797,7 @@ template <class P>
 static int launch_dx(const GroupArgs& A0, int em, int pool_sel, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   ProfScope ps_(pf, PK_DX, gi, st);
+  ps_.name("group_dx_kernel<%s, %d>", P::BF ? "PrecBF" : "PrecF32", em);
   A.pool_sel = pool_sel;
   A.lds_per_wave = 2 * img_bytes(DENSE_CHUNK, P::BF);
   const int lds = 4 * A.lds_per_wave;
@@ -783,6 +820,7 @@ template <class P, int NW>
 static int launch_dw(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   ProfScope ps_(pf, PK_DW, gi, st);
+  ps_.name("group_dw_kernel<%s, %d, %d>", P::BF ? "PrecBF" : "PrecF32", em, NW);
   A.lds_per_wave = 2 * img_bytes(64, P::BF) + 2 * img_bytes(DENSE_CHUNK, P::BF);
   const int lds = NW * A.lds_per_wave;
   int njobs = 0;
@@ -984,12 +1022,13 @@ static int launch_conv_fwd_dma(const GroupArgs& A0, const LayerDesc* layers, int
     F.nkinds = 2;
     for (int k = 0; k < 2 && two; ++k)
       if (build_conv_fwd2_jobs(A, layers, mask[k], 6, F.job[k], &F.has_pool[k], &F.n_red_groups[k])) two = false;
-    const int lds2 = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + ((F.n_red_groups[0] | F.n_red_groups[1]) ? 6 * 4 * 256 * 4 : 0);
+    const int lds2 = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + 4096 + ((F.n_red_groups[0] | F.n_red_groups[1]) ? 6 * 4 * 256 * 4 : 0);
     if (two && lds2 > 80 * 1024) two = false;   // two workgroups must fit one CU
     if (two) {
       F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
       const unsigned grid = (unsigned)(2 * A.cg.S * F.nsplit);
       ProfScope ps_(pf, PK_FWD, gi, st);
+      ps_.name("conv_fwd_dma_kernel<%d, 6, 2>", em);
       return launch_conv_fwd_dma_t<6, 2>(A, F, em, lds2, grid, st);
     }
   }
@@ -998,9 +1037,10 @@ static int launch_conv_fwd_dma(const GroupArgs& A0, const LayerDesc* layers, int
   if (build_conv_fwd2_jobs(A, layers, 0xffu, FW_NC, F.job[0], &F.has_pool[0], &F.n_red_groups[0]))
     return fail(BNN_E_INVALID, "conv fwd plan: jobs exceed %d compute waves", FW_NC);
   F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
-  const int lds = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + (F.n_red_groups[0] > 0 ? FW_NC * 4 * 256 * 4 : 0);
+  const int lds = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + 4096 + (F.n_red_groups[0] > 0 ? FW_NC * 4 * 256 * 4 : 0);
   const unsigned grid = (unsigned)(A.cg.S * F.nsplit);
   ProfScope ps_(pf, PK_FWD, gi, st);
+  ps_.name("conv_fwd_dma_kernel<%d, %d, %d>", em, (int)FW_NC, (int)FW_NL);
   return launch_conv_fwd_dma_t<FW_NC, FW_NL>(A, F, em, lds, grid, st);
 }
 
@@ -1138,6 +1178,7 @@ static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int e
   const int lds = nwi * wbytes;
   const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
   ProfScope ps_(pf, PK_DW, gi, st);
+  ps_.name("conv_dw_mw_kernel<%d, %d, %d>", em, tpw <= 4 ? 4 : (tpw <= 6 ? 6 : 11), nwi);
 #define DISPATCH_NWI(EMV)                                                            \
   (nwi == 4 ? launch_conv_dw_mw_em<EMV, 4>(A, D, lds, grid, st)                      \
             : (nwi == 2 ? launch_conv_dw_mw_em<EMV, 2>(A, D, lds, grid, st) : launch_conv_dw_mw_em<EMV, 1>(A, D, lds, grid, st)))
@@ -1221,6 +1262,7 @@ static int launch_conv_dw_dma(const GroupArgs& A0, const LayerDesc* layers, int 
   const unsigned grid = (unsigned)(D.nkinds * A.cg.S * D.nsplit);
   const int lds = lds_max;
   ProfScope ps_(pf, PK_DW, gi, st);
+  ps_.name("conv_dw_dma_kernel<%d>", em);
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(conv_dw_dma_kernel<EM_PLAIN>, lds));
     conv_dw_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(DW_THREADS), lds, st>>>(A, D);
@@ -1244,6 +1286,7 @@ static int launch_dense_dw_bf(const GroupArgs& A0, int em, hipStream_t st, Prof*
   const int lds = (2 * DN_ROWS * (DN_CH + 8) + 2 * DN_ROWS * (64 + 8)) * 2;
   const unsigned grid = (unsigned)(A.cg.S * nchunk * nsplit);
   ProfScope ps_(pf, PK_DW, gi, st);
+  ps_.name("dense_dw_bf_kernel<%d>", em);
   if (em == EM_PLAIN) dense_dw_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
   else if (em == EM_LRT) dense_dw_bf_kernel<EM_LRT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
   else dense_dw_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
@@ -1309,6 +1352,7 @@ static int launch_conv_dx_dma(const GroupArgs& A0, const LayerDesc* layers, int 
   if (lds > 160 * 1024) return fail(BNN_E_INVALID, "conv dX: %d bytes of LDS", lds);
   const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
   ProfScope ps_(pf, PK_DX, gi, st);
+  ps_.name("conv_dx_dma_kernel<%d>", em);
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(conv_dx_dma_kernel<EM_PLAIN>, lds));
     conv_dx_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(DX_THREADS), lds, st>>>(A, D);
@@ -1319,6 +1363,123 @@ static int launch_conv_dx_dma(const GroupArgs& A0, const LayerDesc* layers, int 
     BNN_TRY(set_lds(conv_dx_dma_kernel<EM_FLIPOUT>, lds));
     conv_dx_dma_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DX_THREADS), lds, st>>>(A, D);
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// fused conv dX (kernels_conv_dx.h): all branches of the group, pooled ones scattered in-kernel
+static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  static thread_local ConvDx2Plan D;   // large; copied into the kernel arguments at launch
+  D = ConvDx2Plan{};
+  const int L = A.g.L, xw = A.g.in_cin_p;
+  const int npt = em == EM_LRT ? 3 : 2;
+  D.ntile = xw / 16;
+  D.nkinds = (D.ntile + DX2_NC - 1) / DX2_NC;
+  int zel = 0, units = 0;
+  int nkd = 0, nkp = 0;   // k-steps of the direct / pooled branches
+  signed char kb[2][DX2_KS], ki[2][DX2_KS];
+  D.dx_t = A.g.in_t + T_GRAD;
+  for (int b = 0; b < A.g.n_branch; ++b) {
+    const BranchDesc& br = A.g.br[b];
+    D.zbase[b] = -1;
+    if (br.dx_t < 0) continue;
+    const LayerDesc& ly = layers[br.layer];
+    if (br.cout % 8 || (16 % (br.cout / 8)) != 0) return fail(BNN_E_INVALID, "conv dX: branch cout %d unsupported", br.cout);
+    if (br.pool) D.has_pool = 1;
+    D.zbase[b] = zel;
+    zel += IMG_ROWS * br.cout;
+    units += L * (br.cout / 8);
+    const int ks = (ly.taps * (ly.cout_p8 / 8) + 3) / 4;
+    int& n = br.pool ? nkp : nkd;
+    for (int i = 0; i < ks; ++i) {
+      if (n >= DX2_KS) return fail(BNN_E_INVALID, "conv dX: more than %d k-steps", DX2_KS);
+      kb[br.pool ? 1 : 0][n] = (signed char)b;
+      ki[br.pool ? 1 : 0][n] = (signed char)i;
+      ++n;
+    }
+  }
+  const int nks = nkd + nkp;
+  // compiled k-step shapes: (5 direct, 1 pooled) and (5 direct, 0 pooled)
+  if (nkd > 5 || nkp > 1) return fail(BNN_E_INVALID, "conv dX: %d direct + %d pooled k-steps", nkd, nkp);
+  for (int i = 0; i < DX2_KS; ++i) D.ks_b[i] = -1;
+  for (int i = 0; i < nkd; ++i) { D.ks_b[i] = kb[0][i]; D.ks_i[i] = ki[0][i]; }
+  for (int i = 0; i < nkp; ++i) { D.ks_b[5 + i] = kb[1][i]; D.ks_i[5 + i] = ki[1][i]; }
+  if (nks == 0) return 0;
+  if (units > DX2_MU * DX2_NW * 64) return fail(BNN_E_INVALID, "conv dX: mask pass needs %d units", units);
+  if (D.has_pool && (!A.amax || (xw % 16) != 0 || ((xw / 16) & (xw / 16 - 1)) != 0))
+    return fail(BNN_E_INVALID, "conv dX: pooled branch without an arg-max plane");
+  if ((xw / 8) & (xw / 8 - 1)) return fail(BNN_E_INVALID, "conv dX: %d input channels", xw);
+  D.nks = nks;
+  D.zelems = zel;
+  const int zbytes = zel * 2, xbytes = em == EM_LRT ? IMG_ROWS * xw * 2 : 0, abytes = D.has_pool ? IMG_ROWS * xw : 0;
+  D.o_x = npt * zbytes;
+  D.o_am = D.o_x + xbytes;
+  D.slot_bytes = (D.o_am + abytes + 15) & ~15;
+  auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+  int ni = 0;
+  auto add_stream = [&](const void* base, uint32_t wstride, uint32_t rstride, int cb, int sh, uint32_t dst) -> int {
+    const int n = L * cb;
+    for (int q0 = 0; q0 < n; q0 += 64) {
+      if (ni >= DX2_MAXI) return fail(BNN_E_INVALID, "conv dX: DMA table overflow");
+      Dx2Inst& I = D.inst[ni++];
+      I.base = base;
+      I.wstride = wstride;
+      I.rstride = rstride;
+      I.dst = dst + (uint32_t)q0 * 16u;
+      I.geom = (uint32_t)q0 | ((uint32_t)ilog2(cb) << 16) | ((uint32_t)sh << 24);
+      I.qn = (uint32_t)n;
+    }
+    return 0;
+  };
+  for (int pt = 0; pt < npt; ++pt)
+    for (int b = 0; b < A.g.n_branch; ++b) {
+      if (D.zbase[b] < 0) continue;
+      const BranchDesc& br = A.g.br[b];
+      if (pt == 1 && !br.relu) continue;
+      const TensorRef tt = pt == 0 ? A.t[br.out_t + T_GRAD] : (pt == 1 ? A.t[br.out_t] : A.t[br.q_t]);
+      if (!tt.p || tt.fmt != TF_BF16) return fail(BNN_E_INVALID, "conv dX: plane %d of branch %d is not bf16", pt, b);
+      const int cb = br.cout / 8;
+      BNN_TRY(add_stream((const char*)tt.p + (size_t)br.out_off * 2, (uint32_t)L * tt.ctot * 2, (uint32_t)tt.ctot * 2, cb,
+                         cb >= 16 ? 0 : ilog2(16 / cb), (uint32_t)(pt * zbytes + (D.zbase[b] + HALO * br.cout) * 2)));
+    }
+  if (em == EM_LRT) {
+    const TensorRef tin = A.t[A.g.in_t];
+    BNN_TRY(add_stream(tin.p, (uint32_t)L * tin.ctot * 2, (uint32_t)tin.ctot * 2, xw / 8, 0, (uint32_t)(D.o_x + HALO * xw * 2)));
+  }
+  if (D.has_pool)
+    BNN_TRY(add_stream(A.amax, (uint32_t)L * xw, (uint32_t)xw, xw / 16, 0, (uint32_t)(D.o_am + HALO * xw)));
+  D.ninst = ni;
+  if ((ni + DX2_NL - 1) / DX2_NL + 1 > 49) return fail(BNN_E_INVALID, "conv dX: %d DMA instructions per window", ni);
+  // slots: 3 (two windows ahead) if two workgroups still share a CU, else 2 if that makes them fit
+  const int extra = 4096;
+  auto total = [&](int ns) { return ns * D.slot_bytes + ns * 256 + extra; };
+  int wg_per_cu = 2;
+  if (total(3) <= 80 * 1024) D.nslots = 3;
+  else if (total(2) <= 80 * 1024) D.nslots = 2;
+  else {
+    wg_per_cu = 1;
+    D.nslots = total(3) <= 160 * 1024 ? 3 : 2;
+  }
+  const int lds = total(D.nslots);
+  if (lds > 160 * 1024) return fail(BNN_E_INVALID, "conv dX: %d bytes of LDS", lds);
+  D.nsplit = std::max(1, std::min(A.cg.B, (256 * wg_per_cu) / std::max(1, A.cg.S * D.nkinds)));
+  const unsigned grid = (unsigned)(A.cg.S * D.nsplit * D.nkinds);
+  ProfScope ps_(pf, PK_DX, gi, st);
+  ps_.name("conv_dx2_kernel<%d, 5, %d>", em, nkp);
+#define LAUNCH_DX2(EMV, KPV)                                                                   \
+  do {                                                                                         \
+    BNN_TRY(set_lds(conv_dx2_kernel<EMV, 5, KPV>, lds));                                       \
+    conv_dx2_kernel<EMV, 5, KPV><<<dim3(grid), dim3(DX2_NW * 64), lds, st>>>(A, D);            \
+  } while (0)
+  if (em == EM_PLAIN) {
+    if (nkp) LAUNCH_DX2(EM_PLAIN, 1); else LAUNCH_DX2(EM_PLAIN, 0);
+  } else if (em == EM_LRT) {
+    if (nkp) LAUNCH_DX2(EM_LRT, 1); else LAUNCH_DX2(EM_LRT, 0);
+  } else {
+    if (nkp) LAUNCH_DX2(EM_FLIPOUT, 1); else LAUNCH_DX2(EM_FLIPOUT, 0);
+  }
+#undef LAUNCH_DX2
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1342,6 +1503,7 @@ static int launch_dense_fwd_dma(const GroupArgs& A0, int em, hipStream_t st, Pro
   const int lds = (FW_SLOTS * 2 + 1) * pbytes + FW_SLOTS * 128 * 4 + FW_NC * 4 * 256 * 4;
   const unsigned grid = (unsigned)A.cg.nwin;
   ProfScope ps_(pf, PK_FWD, gi, st);
+  ps_.name("dense_fwd_dma_kernel<%d>", em);
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(dense_fwd_dma_kernel<EM_PLAIN>, lds));
     dense_fwd_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
@@ -1362,6 +1524,7 @@ static int launch_dense_dx_bf(const GroupArgs& A0, int em, hipStream_t st, Prof*
   const int lds = 2 * DN_ROWS * (zw + 8) * 2;
   const unsigned grid = (unsigned)A.cg.nwin;
   ProfScope ps_(pf, PK_DX, gi, st);
+  ps_.name("dense_dx_bf_kernel<%d>", em);
   if (em == EM_PLAIN) dense_dx_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(1024), lds, st>>>(A);
   else if (em == EM_LRT) dense_dx_bf_kernel<EM_LRT><<<dim3(grid), dim3(1024), lds, st>>>(A);
   else dense_dx_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(1024), lds, st>>>(A);
@@ -1381,6 +1544,7 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
   for (int gi = 0; gi < p->n_groups; ++gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, x, &A);
+    A.dbg = dbg_for(p, PK_FWD, gi);
     if (!bf)
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
@@ -1425,6 +1589,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   for (int gi = p->n_groups - 1; gi >= 0; --gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
+    A.dbg = dbg_for(p, PK_DW, gi);
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
     else if (!A.g.is_dense)
@@ -1441,6 +1606,13 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       (A.g.br[b].pool ? any_pool : any_direct) = true;
     }
     const bool conv_bf = p->d.prec == BNN_PREC_BF16X3 && !A.g.is_dense;
+    if (conv_bf && (any_direct || any_pool) && !getenv("BNN_DX_V1")) {
+      // one launch: direct and pooled branches, arg-max scatter included
+      A.dbg = dbg_for(p, PK_DX, gi);
+      BNN_TRY(launch_conv_dx2(A, p->layers, c->em, c->st, &p->prof, gi));
+      continue;
+    }
+    A.dbg = dbg_for(p, PK_DX, gi);
     if (any_direct) {
       if (p->d.prec == BNN_PREC_F32)
         BNN_TRY(launch_dx<PrecF32>(A, c->em, 0, c->st, &p->prof, gi));
@@ -1452,6 +1624,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       else
         BNN_TRY(launch_dx<PrecBF>(A, c->em, 0, c->st, &p->prof, gi));
     }
+    A.dbg = dbg_for(p, PK_POOLBWD, gi);
     if (any_pool) {
       if (p->d.prec == BNN_PREC_F32)
         BNN_TRY(launch_dx<PrecF32>(A, c->em, 1, c->st, &p->prof, gi));
@@ -1465,6 +1638,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       const int C = p->tens[tin].ctot, L = A.g.L;
       const long n = nwin * L * C;
       ProfScope ps_(&p->prof, PK_POOLBWD, gi, c->st);
+      ps_.name(p->d.prec == BNN_PREC_BF16X3 && (C % 8) == 0 ? "pool_bwd_bf_kernel" : "pool_bwd_kernel");
       if (p->d.prec == BNN_PREC_BF16X3 && (C % 8) == 0) {
         const long n8 = nwin * L * (C / 8);
         pool_bwd_bf_kernel<<<dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, c->st>>>(
@@ -1736,6 +1910,25 @@ extern "C" int bnn_profile_enable(BnnPlan* p, int on) {
   return 0;
 }
 
+// Restricts the recorder to the given tags (n = 0: every launch).  Two events per recorded launch sit
+// between the kernels on the stream, so bench.py's timed region records the dominant symbol only.
+extern "C" int bnn_profile_select(BnnPlan* p, const int32_t* tags, int32_t n) {
+  if (!p || (n > 0 && !tags)) return fail(BNN_E_INVALID, "null argument");
+  p->prof.filter = n > 0;
+  for (bool& b : p->prof.sel) b = false;
+  for (int i = 0; i < n; ++i)
+    if (tags[i] >= 0 && tags[i] < 256) p->prof.sel[tags[i]] = true;
+  return 0;
+}
+
+// Kernel symbol last launched under `tag` while recording (as rocprofv3 prints it, without the argument
+// list); empty if none.
+extern "C" int bnn_profile_name(BnnPlan* p, int32_t tag, char* buf, int32_t cap) {
+  if (!p || !buf || cap <= 0 || tag < 0 || tag >= 256) return fail(BNN_E_INVALID, "bad argument");
+  snprintf(buf, (size_t)cap, "%s", p->prof.names[tag].c_str());
+  return 0;
+}
+
 // Synchronises the recorded events and returns, per (kind, group) tag, the summed duration in
 // milliseconds and the launch count.  tags/ms/count must hold `cap` entries; *n receives the
 // number of distinct tags.  Resets the recorder.
@@ -1762,5 +1955,21 @@ extern "C" int bnn_profile_read(BnnPlan* p, int32_t* tags, double* ms, int64_t* 
   }
   *n = m;
   p->prof.used = 0;
+  return 0;
+}
+
+// diagnostics only (not part of the ABI of include/bayesrul_amd.h): phase time stamps of workgroup 0 of
+// the launch tagged kind * 16 + group (kinds: fwd 0, dx 1, dw 2, pooled dx 7); tag < 0 switches it off.
+extern "C" int bnn_debug_stamps(BnnPlan* p, int tag) {
+  if (!p) return fail(BNN_E_INVALID, "null plan");
+  if (tag >= 0 && !p->dbg_buf) HIP_TRY(hipMalloc((void**)&p->dbg_buf, DBG_STAMP_BYTES));
+  if (p->dbg_buf) HIP_TRY(hipMemset(p->dbg_buf, 0, DBG_STAMP_BYTES));
+  p->dbg_tag = tag;
+  return 0;
+}
+extern "C" int bnn_debug_stamps_read(BnnPlan* p, void* dst, size_t bytes) {
+  if (!p || !p->dbg_buf) return fail(BNN_E_INVALID, "stamps not enabled");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(dst, p->dbg_buf, bytes < (size_t)DBG_STAMP_BYTES ? bytes : (size_t)DBG_STAMP_BYTES, hipMemcpyDeviceToHost));
   return 0;
 }

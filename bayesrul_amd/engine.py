@@ -329,15 +329,28 @@ class SviEngine:
                                               a1, a2, a3, C.c_void_p(self._stream())))
         return out
 
-    def profile(self, on: bool) -> None:
+    KINDS = ["fwd", "dx", "dw", "sample", "head", "finalize", "adam", "pool_bwd", "noise"]
+
+    def profile(self, on: bool, only=None) -> None:
+        """Per-kernel HIP-event timing on the launch stream; `only` = iterable of (kind, group) to
+        restrict the recorder to (two events per recorded launch sit between the kernels)."""
+        tags = [self.KINDS.index(k) * 16 + g for (k, g) in (only or [])]
+        arr = (C.c_int32 * max(1, len(tags)))(*tags)
+        N.check(self.lib.bnn_profile_select(self._plan, arr, len(tags)))
         N.check(self.lib.bnn_profile_enable(self._plan, int(on)))
+
+    def profile_symbol(self, kind: str, group: int) -> str:
+        """Kernel symbol last recorded under (kind, group), as rocprofv3 prints it (no argument list)."""
+        buf = C.create_string_buffer(200)
+        N.check(self.lib.bnn_profile_name(self._plan, self.KINDS.index(kind) * 16 + group, buf, 200))
+        return buf.value.decode()
 
     def profile_read(self) -> Dict[Tuple[str, int], Tuple[float, int]]:
         """{(kind, group): (total ms, launches)} since the last read (HIP events on the stream)."""
         cap = 256
         tags, ms, cnt, n = (C.c_int32 * cap)(), (C.c_double * cap)(), (C.c_int64 * cap)(), C.c_int32()
         N.check(self.lib.bnn_profile_read(self._plan, tags, ms, cnt, cap, C.byref(n)))
-        kinds = ["fwd", "dx", "dw", "sample", "head", "finalize", "adam", "pool_bwd", "noise"]
+        kinds = self.KINDS
         return {(kinds[tags[i] // 16], tags[i] % 16): (ms[i], cnt[i]) for i in range(n.value)}
 
     def tensor(self, which: int) -> torch.Tensor:

@@ -183,6 +183,11 @@ int bnn_export_noise(BnnPlan* plan, const BnnElboArgs* a, uint64_t seed, uint64_
  * tag = kind * 16 + group; kind: 0 group forward, 1 group dX, 2 group dW, 3 weight sampling,
  * 4 head/NLL, 5 gradient finalize, 6 ClippedAdam, 7 max-pool backward. */
 int bnn_profile_enable(BnnPlan* plan, int on);
+/* record only the launches carrying one of `tags` (n = 0: all launches).  Each recorded launch puts two
+ * events on the stream, so a timed region selects the dominant kernel's tags only. */
+int bnn_profile_select(BnnPlan* plan, const int32_t* tags, int32_t n);
+/* kernel symbol (as rocprofv3 prints it, without the argument list) last recorded under `tag` */
+int bnn_profile_name(BnnPlan* plan, int32_t tag, char* buf, int32_t cap);
 int bnn_profile_read(BnnPlan* plan, int32_t* tags, double* ms, int64_t* count, int32_t cap, int32_t* n);
 
 #ifdef __cplusplus
