@@ -916,41 +916,80 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
       sg_ok = true;
     }
   }
-  auto issue = [&](int k) {   // DMA window k of this workgroup into slot k % FW_SLOTS
-    const int wl = win_of(k);
-    const long row0 = (long)(G.in_bcast ? wl : s * B + wl) * L * tin.ctot;
-    char* slot = smem + (k % FW_SLOTS) * 2 * pbytes;
-    int lane_o = lane;
-    asm volatile("" : "+v"(lane_o));
-#define BNN_DMA_ONE(I)                                                                              \
-    {                                                                                               \
-      const int inst = lw + (I) * NL;                                                            \
-      if (inst < 2 * ninst) {                                                                       \
-        const int plane = inst >= ninst ? 1 : 0;                                                    \
-        const int q0 = (inst - plane * ninst) * 64;                                                 \
-        const int q = q0 + lane_o;                                                                  \
-        const int row = q / c8n, pz = q - row * c8n;                                                \
-        const int c8 = pz ^ ((row + HALO) & swm);                                                   \
-        const u16* base = (const u16*)(plane ? tin.lo : tin.p) + row0 + (long)row * tin.ctot + c8 * 8; \
-        char* dst = slot + plane * pbytes + (HALO * RS * 2) + q0 * 16;                              \
-        if (q < nchunk) dma16(base, __builtin_amdgcn_readfirstlane(lds_addr(dst)));               \
-      }                                                                                             \
+  // =========================== loader waves: own code path (own register allocation) ===========================
+  if (is_loader) {
+    // Every DMA instruction of this loader keeps its per-lane source address (window 0 of the workgroup) in a
+    // VGPR pair that advances by `a_step` per issue: the window loop contains no address arithmetic.
+    // issue() must be called for windows 0, 1, 2, ... in order.
+    constexpr int LI = 8;   // instructions per loader (2 planes x ninst <= 16, NL >= 2)
+    const char* a_src[LI];
+    uint32_t a_dst[LI];
+    uint32_t a_on = 0;
+    {
+      const int wl0 = split;
+      const long row0 = (long)(G.in_bcast ? wl0 : s * B + wl0) * L * tin.ctot;
+#pragma unroll
+      for (int i = 0; i < LI; ++i) {
+        a_src[i] = nullptr;
+        a_dst[i] = 0;
+        const int inst = lw + i * NL;
+        if (is_loader && inst < 2 * ninst) {
+          const int plane = inst >= ninst ? 1 : 0;
+          const int q0 = (inst - plane * ninst) * 64;
+          const int q = q0 + lane;
+          const int row = q / c8n, pz = q - row * c8n;
+          const int c8 = pz ^ ((row + HALO) & swm);
+          a_src[i] = (const char*)((const u16*)(plane ? tin.lo : tin.p) + row0 + (long)row * tin.ctot + c8 * 8);
+          a_dst[i] = (uint32_t)(plane * pbytes + (HALO * RS * 2) + q0 * 16);
+          if (q < nchunk) a_on |= 1u << i;
+        }
+      }
     }
-    BNN_DMA_ONE(0)
-    BNN_DMA_ONE(1)
-    BNN_DMA_ONE(2)
-    BNN_DMA_ONE(3)
-    if (NL < 4) {
-      BNN_DMA_ONE(4)
-      BNN_DMA_ONE(5)
-      BNN_DMA_ONE(6)
-      BNN_DMA_ONE(7)
+    const long a_step = (long)F.nsplit * L * tin.ctot * 2;
+    const long sg_step = (long)F.nsplit * sg_stride;
+    if (sg_ok) sg_src += ((long)s * B + split) * sg_stride;
+    // all ordinary loads of the loader state are consumed here (a compiler-placed vmcnt wait inside the
+    // issue sequence would serialise the unmodelled DMAs)
+    asm volatile("" : "+v"(sg_src));
+    const uint32_t lds0 = lds_addr(smem);
+    auto issue = [&](int k) {   // DMA the next window (k) of this workgroup into slot k % FW_SLOTS
+      const uint32_t sbase = lds0 + (uint32_t)((k % FW_SLOTS) * 2 * pbytes);
+#pragma unroll
+      for (int i = 0; i < LI; ++i) {
+        if (lw + i * NL >= 2 * ninst) break;
+        uint32_t on = a_on;
+        asm volatile("" : "+v"(on));
+        if ((on >> i) & 1u) dma16(a_src[i], __builtin_amdgcn_readfirstlane(sbase + a_dst[i]));
+        a_src[i] += a_step;
+      }
+      if (EM == EM_FLIPOUT && lw == 0) {
+        if (sg_ok) dma4(sg_src, lds0 + (uint32_t)((FW_SLOTS * 2 + 4) * pbytes + (k % FW_SLOTS) * 256));
+        sg_src += sg_step;
+      }
+    };
+    if (EM == EM_FLIPOUT) build_sign_lut(lut, tid, NTHR);
+    __syncthreads();  // zero fill visible
+    BNN_STAMP_DECL(A);
+    if (nwin > 0) issue(0);
+    if (nwin > 1) issue(1);
+    const bool derive = (has_pool || LRT) && !(A.pool_sel & 2);
+    const int nfly = my_ninst + ((EM == EM_FLIPOUT && lw == 0) ? 1 : 0);   // DMAs of one window
+    for (int k = 0; k < nwin; ++k) {
+      stamp(k, 0);
+      // window k landed: all but the DMAs of window k+1 are complete
+      if (k + 1 < nwin) BNN_WAIT_VMCNT(nfly);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(k, 1);
+      lds_barrier();                                // B1
+      stamp(k, 2);
+      if (derive) lds_barrier();                    // B2 (derived planes are built by the compute waves)
+      stamp(k, 4);
+      if (k + 2 < nwin) issue(k + 2);               // slot (k+2)%3 == (k-1)%3: free since B1
+      stamp(k, 5);
+      if (n_red_groups > 0) lds_barrier();          // K-split reduction barrier
     }
-#undef BNN_DMA_ONE
-    if (EM == EM_FLIPOUT && lw == 0) {
-      if (sg_ok) dma4(sg_src + ((long)s * B + wl) * sg_stride, __builtin_amdgcn_readfirstlane(lds_addr(sgn + (k % FW_SLOTS) * 64)));
-    }
-  };
+    return;
+  }
 
   // =========================== compute state ===========================
   const int i16 = lane & 15, g4 = lane >> 4;
@@ -1028,10 +1067,6 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
   // =========================== prologue ===========================
   if (EM == EM_FLIPOUT) build_sign_lut(lut, tid, NTHR);
   __syncthreads();  // zero fill visible
-  if (is_loader) {
-    if (nwin > 0) issue(0);
-    if (nwin > 1) issue(1);
-  }
 
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   BNN_STAMP_DECL(A);
@@ -1040,14 +1075,6 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
     const int slot = k % FW_SLOTS;
     u16* r_hi = raw + slot * pbytes;             // 2 planes per slot: elements = 2*pbytes/2
     u16* r_lo = r_hi + (pbytes >> 1);
-    // ---- window k landed? (loaders: all but the DMAs of window k+1 are complete) ----
-    if (is_loader) {
-      const bool more = (k + 1 < nwin);
-      // my_ninst (+1 sign DMA for loader 0) instructions per window may stay in flight
-      const int nfly = my_ninst + ((EM == EM_FLIPOUT && lw == 0) ? 1 : 0);
-      if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else BNN_WAIT_VMCNT(nfly);
-    }
     stamp(k, 1);
     lds_barrier();                                // B1: raw planes of window k visible; compute(k-1) finished
     stamp(k, 2);
@@ -1130,9 +1157,6 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
       stamp(k, 3);
       lds_barrier();                              // B2: derived planes visible
       stamp(k, 4);
-    }
-    if (is_loader) {
-      if (k + 2 < nwin) issue(k + 2);             // slot (k+2)%3 == (k-1)%3: free since B1
     }
     // ---------------- MFMA (compute waves) ----------------
     f32x4 acc_a[2], acc_b[2];
@@ -1660,37 +1684,70 @@ __global__ __launch_bounds__(FW_THREADS) void dense_fwd_dma_kernel(const GroupAr
   const bool is_loader = wave >= FW_NC;
   const int lw = wave - FW_NC;
   const int nchunk = F.nchunk;
-  // loaders: 2 planes x 16 instructions (32 rows x 16 chunks of 16 B), 8 per ... 4 per loader
-  auto issue = [&](int c) {
-    char* slot = smem + (c % FW_SLOTS) * 2 * pbytes;
-    const int cw8 = min(DN_CH, br.cin_p - c * DN_CH) >> 3;   // valid 16-byte chunks per row
-    int lane_o = lane;
-    asm volatile("" : "+v"(lane_o));
+  // =========================== loader waves: own code path ===========================
+  // 2 planes x 8 instructions (32 rows x 16 chunks of 16 B = 8 KB) per K-chunk, 4 per loader.  Every instruction
+  // keeps its per-lane source address in a VGPR pair that advances by one chunk (256 B) per issue; the
+  // lane predicate only differs in the last, partial chunk.  issue() is called for chunks 0, 1, 2, ...
+  if (is_loader) {
+    const char* a_src[4];
+    uint32_t a_dst[4];
+    uint32_t on_last = 0;
+    const int cw8_last = (br.cin_p - (nchunk - 1) * DN_CH) >> 3;   // valid 16-byte chunks per row of the last chunk
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int inst = lw + i * FW_NL;                 // 0..31: plane = inst >> 4
-      const int plane = inst >> 4, q0 = (inst & 15) * 64;
-      const int q = q0 + lane_o;
+    for (int i = 0; i < 4; ++i) {
+      const int inst = lw + i * FW_NL;                 // 0..15: plane = inst >> 3
+      const int plane = inst >> 3, q0 = (inst & 7) * 64;
+      const int q = q0 + lane;
       const int row = q >> 4, p = q & 15;
       const int c8 = p ^ (row & 15);
       // rows beyond the last valid one re-read that row: every instruction keeps active lanes
       // (the counted vmcnt wait relies on it); their results are never stored
       const int srow = min(row, W.nvalid - 1);
-      const u16* src = (const u16*)(plane ? tin.lo : tin.p) + (long)(W.in_row0 + srow) * tin.ctot + c * DN_CH + c8 * 8;
-      char* dst = slot + plane * pbytes + q0 * 16;
-      if (c8 < cw8) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
+      a_src[i] = (const char*)((const u16*)(plane ? tin.lo : tin.p) + (long)(W.in_row0 + srow) * tin.ctot + c8 * 8);
+      a_dst[i] = (uint32_t)(plane * pbytes + q0 * 16);
+      if (c8 < cw8_last) on_last |= 1u << i;
     }
+    // flipout sign_in words of a chunk: lane -> (row, word): 128 lanes over loaders 0 and 1
+    const uint32_t* sg_src = nullptr;
+    int sg_n = 0;   // chunks for which this lane's word exists
     if (EM == EM_FLIPOUT && lw < 2) {
-      // sign_in words of this chunk: lane -> (row, word): 128 lanes over loaders 0 and 1
-      const int q = lw * 64 + lane_o;
+      const int q = lw * 64 + lane;
       const int row = q >> 2, k = q & 3;
       const int srow = min(row, W.nvalid - 1);
-      const uint32_t* src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + (long)(W.ex0 + srow) * ly.sign_in_words + c * 4 + k;
-      if (c * 4 + k < ly.sign_in_words)
-        dma4(src, __builtin_amdgcn_readfirstlane(lds_addr(sgn + (c % FW_SLOTS) * 128 + lw * 64)));
+      sg_src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + (long)(W.ex0 + srow) * ly.sign_in_words + k;
+      sg_n = (ly.sign_in_words - k + 3) >> 2;
     }
-  };
-  const int n_issue = 8 + ((EM == EM_FLIPOUT && lw < 2) ? 1 : 0);
+    asm volatile("" : "+v"(sg_src), "+v"(sg_n));   // loads consumed before the DMA sequence (no vmcnt wait inside it)
+    const uint32_t lds0 = lds_addr(smem);
+    auto issue = [&](int c) {
+      const uint32_t sbase = lds0 + (uint32_t)((c % FW_SLOTS) * 2 * pbytes);
+      const bool last = c == nchunk - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t on = on_last;
+        asm volatile("" : "+v"(on));
+        if (!last || ((on >> i) & 1u)) dma16(a_src[i], __builtin_amdgcn_readfirstlane(sbase + a_dst[i]));
+        a_src[i] += DN_CH * 2;
+      }
+      if (EM == EM_FLIPOUT && lw < 2) {
+        if (c < sg_n) dma4(sg_src, lds0 + (uint32_t)((FW_SLOTS * 2 + 1) * pbytes + ((c % FW_SLOTS) * 128 + lw * 64) * 4));
+        sg_src += 4;
+      }
+    };
+    const int n_issue = 4 + ((EM == EM_FLIPOUT && lw < 2) ? 1 : 0);
+    __syncthreads();
+    if (nchunk > 0) issue(0);
+    if (nchunk > 1) issue(1);
+    for (int c = 0; c < nchunk; ++c) {
+      if (c + 1 < nchunk) BNN_WAIT_VMCNT(n_issue);
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();   // B1
+      if constexpr (LRT) lds_barrier();  // B2
+      if (c + 2 < nchunk) issue(c + 2);
+    }
+    if (F.members > 1) lds_barrier();
+    return;
+  }
 
   // =========================== compute state ===========================
   const int i16 = lane & 15, g4 = lane >> 4;
@@ -1720,19 +1777,11 @@ __global__ __launch_bounds__(FW_THREADS) void dense_fwd_dma_kernel(const GroupAr
   }
 
   __syncthreads();
-  if (is_loader) {
-    if (nchunk > 0) issue(0);
-    if (nchunk > 1) issue(1);
-  }
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   for (int c = 0; c < nchunk; ++c) {
     const int slot = c % FW_SLOTS;
     const u16* r_hi = raw + slot * pbytes;
     const u16* r_lo = r_hi + (pbytes >> 1);
-    if (is_loader) {
-      if (c + 1 < nchunk) BNN_WAIT_VMCNT(n_issue);
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     lds_barrier();   // B1: chunk c visible, chunk c-1 consumed
     if constexpr (LRT) {
       // squares of the bf16 hi plane (what the variance contraction sees)
@@ -1748,9 +1797,6 @@ __global__ __launch_bounds__(FW_THREADS) void dense_fwd_dma_kernel(const GroupAr
         *(uint4*)&sqi[U * 8] = make_uint4(o[0], o[1], o[2], o[3]);
       }
       lds_barrier();  // B2
-    }
-    if (is_loader) {
-      if (c + 2 < nchunk) issue(c + 2);
     }
     if (has_job && (c % F.members) == mem) {
       const int nks = min(DN_CH, br.cin_p - c * DN_CH) >> 5;

@@ -947,7 +947,10 @@ static int build_conv_fwd2_jobs(const GroupArgs& A, const LayerDesc* layers, uns
     }
   }
   if (njobs > nc) return 1;   // does not fit: caller falls back
-  while (njobs < nc) {
+  // optional splits only where a K-split reduction (one more barrier per window) is needed anyway
+  bool any_split = false;
+  for (const Tile& t : tiles) any_split |= t.nm > 1;
+  while (any_split && njobs < nc) {
     int best = -1;
     double bv = 1.0;
     for (size_t t = 0; t < tiles.size(); ++t) {
@@ -1549,7 +1552,7 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
       BNN_TRY((getenv("BNN_FWD_REGSTAGE") ? launch_conv_fwd_bf : launch_conv_fwd_dma)(A, p->layers, c->em, c->st, &p->prof, gi));
-    else if (dense_dma_ok(A))
+    else if (dense_dma_ok(A) && !getenv("BNN_DENSE_GENERIC"))
       BNN_TRY(launch_dense_fwd_dma(A, c->em, c->st, &p->prof, gi));
     else
       BNN_TRY(launch_fwd<PrecBF>(A, c->em, c->st, &p->prof, gi));
