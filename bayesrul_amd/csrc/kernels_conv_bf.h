@@ -1736,14 +1736,19 @@ __global__ __launch_bounds__(FW_THREADS) void dense_fwd_dma_kernel(const GroupAr
     };
     const int n_issue = 4 + ((EM == EM_FLIPOUT && lw < 2) ? 1 : 0);
     __syncthreads();
+    BNN_STAMP_DECL(A);
     if (nchunk > 0) issue(0);
     if (nchunk > 1) issue(1);
     for (int c = 0; c < nchunk; ++c) {
+      stamp(c, 0);
       if (c + 1 < nchunk) BNN_WAIT_VMCNT(n_issue);
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(c, 1);
       lds_barrier();   // B1
+      stamp(c, 2);
       if constexpr (LRT) lds_barrier();  // B2
       if (c + 2 < nchunk) issue(c + 2);
+      stamp(c, 3);
     }
     if (F.members > 1) lds_barrier();
     return;
@@ -1778,11 +1783,14 @@ __global__ __launch_bounds__(FW_THREADS) void dense_fwd_dma_kernel(const GroupAr
 
   __syncthreads();
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  BNN_STAMP_DECL(A);
   for (int c = 0; c < nchunk; ++c) {
+    stamp(c, 0);
     const int slot = c % FW_SLOTS;
     const u16* r_hi = raw + slot * pbytes;
     const u16* r_lo = r_hi + (pbytes >> 1);
     lds_barrier();   // B1: chunk c visible, chunk c-1 consumed
+    stamp(c, 2);
     if constexpr (LRT) {
       // squares of the bf16 hi plane (what the variance contraction sees)
       for (int U = tid; U < DN_ROWS * 16; U += FW_THREADS) {
@@ -1829,7 +1837,9 @@ __global__ __launch_bounds__(FW_THREADS) void dense_fwd_dma_kernel(const GroupAr
           }
         }
       }
+      stamp(c, 3);
       if (c + F.members < nchunk) load_w(c + F.members);   // lands while the other members work
+      stamp(c, 4);
     }
   }
   // ---------------- reduction over the members of an n-tile ----------------
@@ -2714,13 +2724,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs 
   };
 
   BNN_STAMP_DECL(A);
-  for (int k0 = 0; k0 < my_nwin; k0 += NWI) {
+  // registers of one iteration's loads; the NEXT iteration's loads are issued right after the staging
+  // stores, so their latency hides behind the pooled-copy pass and the MFMA phase
+  uint4 px[NWI], pz[NWI][2], py[NWI][2], pq[NWI][2];
+  uint32_t psg[NWI];
+  auto load_iter = [&](int k0) {
     const int nw = min(NWI, my_nwin - k0);
-    const int kst = k0 / NWI;
-    stamp(kst, 0);
-    // ---- issue every load of the iteration, then consume ----
-    uint4 px[NWI], pz[NWI][2], py[NWI][2], pq[NWI][2];
-    uint32_t psg[NWI];
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
       px[i] = make_uint4(0, 0, 0, 0);
@@ -2743,6 +2752,15 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs 
           }
       }
     }
+  };
+  // 11 tiles per wave leave no registers for the early loads (they would spill): load at the top instead
+  constexpr bool PF = MAXT < 11;
+  if (PF && my_nwin > 0) load_iter(0);
+  for (int k0 = 0; k0 < my_nwin; k0 += NWI) {
+    const int nw = min(NWI, my_nwin - k0);
+    const int kst = k0 / NWI;
+    stamp(kst, 0);
+    if (!PF) load_iter(k0);
     stamp(kst, 1);
     __syncthreads();   // previous iteration's images consumed
     stamp(kst, 2);
@@ -2768,6 +2786,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs 
         }
     }
     stamp(kst, 3);
+    if (PF && k0 + NWI < my_nwin) load_iter(k0 + NWI);
     __syncthreads();
     stamp(kst, 4);
     if (D.has_pool && !(A.pool_sel & 2)) {
