@@ -17,6 +17,7 @@
 #include "kernels_misc.h"
 #include "kernels_conv_bf.h"
 #include "kernels_conv_dx.h"
+#include "kernels_dense_fwd.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -1521,6 +1522,33 @@ static int launch_dense_fwd_dma(const GroupArgs& A0, int em, hipStream_t st, Pro
   return 0;
 }
 
+// one-branch dense forward, 6-wave workgroups without K split (kernels_dense_fwd.h)
+static int launch_dense_fwd2(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  DenseFwd2Plan F{};
+  const BranchDesc& br = A.g.br[0];
+  F.ntile = br.ntiles;
+  F.nchunk = (br.cin_p + DF_CH - 1) / DF_CH;
+  if (F.ntile > DF_NC) return fail(BNN_E_INVALID, "dense fwd: %d n-tiles", F.ntile);
+  const int slot_bytes = 2 * DF_ROWS * DF_CH * 2 + DF_ROWS * 4 * 4;
+  const int lds = DF_SLOTS * slot_bytes + (em == EM_LRT ? DF_ROWS * DF_CH * 2 : 0) + (em == EM_FLIPOUT ? 4096 : 0);
+  const unsigned grid = (unsigned)(((A.cg.nwin + 7) / 8) * 8);   // XCD-aware window order inside the kernel
+  ProfScope ps_(pf, PK_FWD, gi, st);
+  ps_.name("dense_fwd2_kernel<%d>", em);
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(dense_fwd2_kernel<EM_PLAIN>, lds));
+    dense_fwd2_kernel<EM_PLAIN><<<dim3(grid), dim3(DF_NW * 64), lds, st>>>(A, F);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(dense_fwd2_kernel<EM_LRT>, lds));
+    dense_fwd2_kernel<EM_LRT><<<dim3(grid), dim3(DF_NW * 64), lds, st>>>(A, F);
+  } else {
+    BNN_TRY(set_lds(dense_fwd2_kernel<EM_FLIPOUT>, lds));
+    dense_fwd2_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DF_NW * 64), lds, st>>>(A, F);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int launch_dense_dx_bf(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   const int zw = rup(A.g.br[0].cout, 32);
@@ -1553,7 +1581,7 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
     else if (!A.g.is_dense)
       BNN_TRY((getenv("BNN_FWD_REGSTAGE") ? launch_conv_fwd_bf : launch_conv_fwd_dma)(A, p->layers, c->em, c->st, &p->prof, gi));
     else if (dense_dma_ok(A) && !getenv("BNN_DENSE_GENERIC"))
-      BNN_TRY(launch_dense_fwd_dma(A, c->em, c->st, &p->prof, gi));
+      BNN_TRY((getenv("BNN_DENSE_V1") ? launch_dense_fwd_dma : launch_dense_fwd2)(A, c->em, c->st, &p->prof, gi));
     else
       BNN_TRY(launch_fwd<PrecBF>(A, c->em, c->st, &p->prof, gi));
   }
