@@ -38,709 +38,15 @@ __device__ __forceinline__ bf16x8 xor_sign(bf16x8 v, bool neg) {
   return __builtin_bit_cast(bf16x8, u);
 }
 
-// MAXT: dW tiles per wave; XU / ZU: float4 staging units per thread for X / dZ
-template <int EM, int MAXT, int XU, int ZU>
-__global__ __launch_bounds__(CV_THREADS) void conv_dw_bf_kernel(const GroupArgs A, const ConvDwPlan D) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool DUAL = (EM != EM_PLAIN);
-  constexpr bool LRT = (EM == EM_LRT);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> tile data in SGPRs
-  const GroupDesc& G = A.g;
-  const int s = blockIdx.x / D.nsplit, split = blockIdx.x - s * D.nsplit;
-  const int L = G.L, B = A.cg.B;
-  const int cwp = G.in_cin_p;               // all channels of the input tensor view
-  const int xw16 = (cwp + 15) & ~15;
-  const int RSx = img_row_stride(xw16, true), RSz = img_row_stride(D.zw, true);
-  const int xbytes = (IMG_ROWS * RSx * 2 + 15) & ~15, zbytes = (IMG_ROWS * RSz * 2 + 15) & ~15;
-  u16* x_hi = (u16*)smem;
-  u16* xp_hi = (u16*)(smem + xbytes);
-  u16* x_sq = (u16*)(smem + 2 * xbytes);
-  u16* xp_sq = (u16*)(smem + 3 * xbytes);
-  u16* dz = (u16*)(smem + 4 * xbytes);
-  u16* dz2 = (u16*)(smem + 4 * xbytes + zbytes);
-  // zero everything once: halo rows / pad channels are never written again
-  {
-    const int total = (4 * xbytes + 2 * zbytes) >> 2;
-    uint32_t* z = (uint32_t*)smem;
-    for (int k = tid; k < total; k += CV_THREADS) z[k] = 0u;
-  }
-  const TensorRef tin = A.t[G.in_t];
-  const int xc4 = cwp >> 2, zc4 = D.zw >> 2;
-  const int xunits = L * xc4, zunits = L * zc4;
-
-  // ---- per-thread staging plan (fixed for all windows) ----
-  int x_src[XU], x_dst[XU];
-  bool x_ok[XU];
-#pragma unroll
-  for (int u = 0; u < XU; ++u) {
-    const int unit = tid + u * CV_THREADS;
-    x_ok[u] = unit < xunits;
-    const int row = unit / xc4, c = (unit - row * xc4) * 4;
-    x_src[u] = row * tin.ctot + c;
-    x_dst[u] = (row + HALO) * RSx + c;
-    if (c + 4 > tin.ctot && x_ok[u]) x_ok[u] = (c < tin.ctot);  // partial handled in loader
-  }
-  int z_src[ZU], z_dst[ZU], z_nv[ZU];
-  const u16* z_g[ZU];   // bf16 planes resolved once: dY, Y hi (relu mask; null: none), q (LRT)
-  const u16* z_y[ZU];
-  const u16* z_q[ZU];
-  int z_ct[ZU];
-#pragma unroll
-  for (int u = 0; u < ZU; ++u) {
-    const int unit = tid + u * CV_THREADS;
-    z_nv[u] = 0;
-    z_src[u] = z_dst[u] = z_ct[u] = 0;
-    z_g[u] = z_y[u] = z_q[u] = nullptr;
-    if (unit < zunits) {
-      const int row = unit / zc4, zc = (unit - row * zc4) * 4;
-      int b = 0;
-      for (int k = 1; k < G.n_branch; ++k)
-        if (zc >= D.zoff[k]) b = k;
-      const BranchDesc& br = G.br[b];
-      const int c = zc - D.zoff[b];
-      const int nv = min(4, br.cout - c);
-      if (nv > 0) {
-        const TensorRef tg = A.t[br.out_t + T_GRAD];
-        z_nv[u] = nv;
-        z_ct[u] = tg.ctot;
-        z_src[u] = row * tg.ctot + br.out_off + c;
-        z_dst[u] = (row + HALO) * RSz + zc;
-        z_g[u] = (const u16*)tg.p;
-        z_y[u] = br.relu ? (const u16*)A.t[br.out_t].p : nullptr;
-        z_q[u] = LRT ? (const u16*)A.t[br.q_t].p : nullptr;
-      }
-    }
-  }
-  // ---- per-wave tiles: everything that does not depend on the window is hoisted ----
-  f32x4 acc_a[MAXT], acc_b[MAXT];
-  int t_a[MAXT], t_b[MAXT];        // LDS element offsets of the first tr-read of A / B
-  // flipout (all wave-uniform): pointer to the sign word of example 0 that holds this tile's 16
-  // lanes, words per example, bit of lane 0
-  const uint32_t* t_sop[MAXT];
-  const uint32_t* t_sip[MAXT];
-  int t_sow[MAXT], t_siw[MAXT], t_so[MAXT], t_si[MAXT];
-  bool t_ok[MAXT];
-#pragma unroll
-  for (int m = 0; m < MAXT; ++m) {
-    acc_a[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc_b[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int t = wave + CV_WAVES * m;
-    t_ok[m] = t < D.ntiles;
-    t_a[m] = t_b[m] = t_so[m] = t_si[m] = t_sow[m] = t_siw[m] = 0;
-    t_sop[m] = t_sip[m] = nullptr;
-    if (t_ok[m]) {
-      const DwTile T = D.tile[t];
-      const BranchDesc& br = G.br[T.b];
-      const LayerDesc& ly = A.layers[br.layer];
-      const int n0 = D.zoff[T.b] + T.nt * 16;
-      const int c0 = br.in_off + T.ct * 16;
-      const int tshift = T.tap - ly.pad;
-      const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-      const int r0 = 8 * g + q;
-      t_a[m] = (r0 + HALO) * RSz + n0 + 4 * p;
-      t_b[m] = (br.pool ? (xbytes >> 1) : 0) + (r0 + tshift + HALO) * RSx + c0 + 4 * p;  // xp_hi follows x_hi
-      const int nbit = br.n_off + T.nt * 16;  // lane l adds (l & 15): same 32-bit word for all lanes
-      const int cbit = T.ct * 16;
-      t_so[m] = nbit & 31;
-      t_si[m] = cbit & 31;
-      t_sop[m] = A.nz.sign_out + ly.sign_out_off * A.nz.examples + (nbit >> 5);
-      t_sip[m] = A.nz.sign_in + ly.sign_in_off * A.nz.examples + (cbit >> 5);
-      t_sow[m] = ly.sign_out_words;
-      t_siw[m] = ly.sign_in_words;
-    }
-  }
-  float gb_a = 0.f, gb_b = 0.f;
-  uint32_t sg_o[MAXT], sg_i[MAXT];  // prefetched sign words of the next window
-
-  f32x4 px[XU], pz[ZU], pq[ZU];
-  const bool x_vec = ((tin.ctot & 3) == 0);
-  auto prefetch = [&](int wl) {
-    const int w = s * B + wl;
-    const long xrow0 = (long)(G.in_bcast ? wl : w) * L;
-    const long zrow0 = (long)w * L;
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      px[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (x_ok[u]) {
-        px[u] = unpack_bf4(*(const uint2*)((const u16*)tin.p + xrow0 * tin.ctot + x_src[u]));
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < ZU; ++u) {
-      pz[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      pq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (z_nv[u] > 0) {
-        const long o = zrow0 * z_ct[u] + z_src[u];
-        f32x4 g = unpack_bf4(*(const uint2*)(z_g[u] + o));   // channel pads of the tensors are zero
-        if (z_y[u]) {
-          const f32x4 y = unpack_bf4(*(const uint2*)(z_y[u] + o));
-#pragma unroll
-          for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? g[k] : 0.f;
-        }
-        pz[u] = g;
-        if constexpr (LRT) pq[u] = unpack_bf4(*(const uint2*)(z_q[u] + o));
-      }
-    }
-    if constexpr (EM == EM_FLIPOUT) {
-#pragma unroll
-      for (int m = 0; m < MAXT; ++m) {
-        sg_o[m] = sg_i[m] = 0u;
-        if (t_ok[m]) {
-          sg_o[m] = t_sop[m][(long)w * t_sow[m]];
-          sg_i[m] = t_sip[m][(long)w * t_siw[m]];
-        }
-      }
-    }
-  };
-
-  const int pp = B;  // windows per particle (conv groups)
-  int wl = split;
-  if (wl < pp) prefetch(wl);
-  for (; wl < pp; wl += D.nsplit) {
-    __syncthreads();  // previous window fully consumed (and the initial zero fill is visible)
-#pragma unroll
-    for (int u = 0; u < XU; ++u)
-      if (tid + u * CV_THREADS < xunits) {
-        *(uint2*)&x_hi[x_dst[u]] = pack_bf4(px[u]);
-        if constexpr (LRT) {
-          f32x4 q;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float xb = bf2f(f2bf(px[u][k]));
-            q[k] = xb * xb;
-          }
-          *(uint2*)&x_sq[x_dst[u]] = pack_bf4(q);
-        }
-      }
-#pragma unroll
-    for (int u = 0; u < ZU; ++u)
-      if (tid + u * CV_THREADS < zunits) {
-        *(uint2*)&dz[z_dst[u]] = pack_bf4(pz[u]);
-        if constexpr (LRT) {
-          f32x4 q;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) q[k] = pz[u][k] * pq[u][k];
-          *(uint2*)&dz2[z_dst[u]] = pack_bf4(q);
-        }
-      }
-    __syncthreads();
-    if (D.has_pool) {
-      // pooled image from the bf16 image: rounding is monotone, so max commutes with it
-      for (int unit = tid; unit < xunits; unit += CV_THREADS) {
-        const int row = unit / xc4, c = (unit - row * xc4) * 4;
-        const int o = (row + HALO) * RSx + c;
-        uint2 v0 = *(const uint2*)&x_hi[o];
-        u16 h[4] = {(u16)(v0.x & 0xffff), (u16)(v0.x >> 16), (u16)(v0.y & 0xffff), (u16)(v0.y >> 16)};
-        float m[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) m[k] = bf2f(h[k]);
-        if (row > 0) {
-          const uint2 a = *(const uint2*)&x_hi[o - RSx];
-          m[0] = fmaxf(m[0], bf2f((u16)(a.x & 0xffff))); m[1] = fmaxf(m[1], bf2f((u16)(a.x >> 16)));
-          m[2] = fmaxf(m[2], bf2f((u16)(a.y & 0xffff))); m[3] = fmaxf(m[3], bf2f((u16)(a.y >> 16)));
-        }
-        if (row + 1 < L) {
-          const uint2 a = *(const uint2*)&x_hi[o + RSx];
-          m[0] = fmaxf(m[0], bf2f((u16)(a.x & 0xffff))); m[1] = fmaxf(m[1], bf2f((u16)(a.x >> 16)));
-          m[2] = fmaxf(m[2], bf2f((u16)(a.y & 0xffff))); m[3] = fmaxf(m[3], bf2f((u16)(a.y >> 16)));
-        }
-        *(uint2*)&xp_hi[o] = pack_bf4(f32x4{m[0], m[1], m[2], m[3]});
-        if constexpr (LRT) *(uint2*)&xp_sq[o] = pack_bf4(f32x4{m[0] * m[0], m[1] * m[1], m[2] * m[2], m[3] * m[3]});
-      }
-      __syncthreads();
-    }
-    // sign words of THIS window were prefetched with its activations; keep a copy because the
-    // prefetch of the next window (issued below) overwrites the registers
-    bool neg_o[MAXT], neg_i[MAXT];
-    if constexpr (EM == EM_FLIPOUT) {
-#pragma unroll
-      for (int m = 0; m < MAXT; ++m) {
-        neg_o[m] = (sg_o[m] >> (t_so[m] + (lane & 15))) & 1u;
-        neg_i[m] = (sg_i[m] >> (t_si[m] + (lane & 15))) & 1u;
-      }
-    }
-    if (wl + D.nsplit < pp) prefetch(wl + D.nsplit);  // in flight during the MFMAs below
-#pragma unroll
-    for (int m = 0; m < MAXT; ++m) {
-      if (t_ok[m]) {
-        const u16* a0 = dz + t_a[m];
-        const u16* b0 = x_hi + t_b[m];
-        const bf16x8 fa = tr_frag(a0, a0 + 4 * RSz);
-        const bf16x8 fb = tr_frag(b0, b0 + 4 * RSx);
-        acc_a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc_a[m], 0, 0, 0);
-        if constexpr (LRT) {
-          const u16* a2 = dz2 + t_a[m];
-          const u16* b2 = x_sq + t_b[m];  // xp_sq follows x_sq at the same distance
-          acc_b[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(a2, a2 + 4 * RSz), tr_frag(b2, b2 + 4 * RSx),
-                                                             acc_b[m], 0, 0, 0);
-        } else if constexpr (EM == EM_FLIPOUT) {
-          acc_b[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xor_sign(fa, neg_o[m]), xor_sign(fb, neg_i[m]), acc_b[m],
-                                                             0, 0, 0);
-        }
-      }
-    }
-    if (tid < D.zw) {
-      float sa = 0.f, sb = 0.f;
-      for (int r = 0; r < L; ++r) {
-        sa += bf2f(dz[(r + HALO) * RSz + tid]);
-        if constexpr (LRT) sb += bf2f(dz2[(r + HALO) * RSz + tid]);
-      }
-      gb_a += sa;
-      gb_b += sb;
-    }
-  }
-  // ---- write out ----
-  const int i4 = 4 * (lane >> 4), jc = lane & 15;
-#pragma unroll
-  for (int m = 0; m < MAXT; ++m) {
-    const int t = wave + CV_WAVES * m;
-    if (t >= D.ntiles) continue;
-    const DwTile T = D.tile[t];
-    const BranchDesc& br = G.br[T.b];
-    const LayerDesc& ly = A.layers[br.layer];
-    const int c = T.ct * 16 + jc;
-    if (c >= br.cin_p) continue;
-    float* gwa = A.gw_a + A.gw_stride * s + ly.w_off;
-    float* gwb = A.gw_b + A.gw_stride * s + ly.w_off;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = T.nt * 16 + i4 + r;
-      if (n >= br.cout) continue;
-      const long o = (long)(br.n_off + n) * ly.KP + (long)T.tap * ly.cin_img + c;
-      atomicAdd(gwa + o, acc_a[m][r]);
-      if constexpr (DUAL) atomicAdd(gwb + o, acc_b[m][r]);
-    }
-  }
-  if (tid < D.zw) {
-    int b = 0;
-    for (int k = 1; k < G.n_branch; ++k)
-      if (tid >= D.zoff[k]) b = k;
-    const BranchDesc& br = G.br[b];
-    const int n = tid - D.zoff[b];
-    if (n < br.cout) {
-      const LayerDesc& ly = A.layers[br.layer];
-      atomicAdd(A.gb_a + (long)A.gb_stride * s + ly.bias_off + br.n_off + n, gb_a);
-      if constexpr (LRT) atomicAdd(A.gb_b + (long)A.gb_stride * s + ly.bias_off + br.n_off + n, gb_b);
-    }
-  }
-}
-
-// ==========================================================================================
-// conv_fwd_bf_kernel : variational forward of a conv group, all branches, bf16 planes.
-//   * the (n-tile, k-step range) JOBS of a wave and their weight fragments (hi, lo, B slot) live
-//     in registers for the whole kernel; windows stream through one shared LDS image set;
-//   * staging = straight 16-byte copies of the bf16 hi/lo planes, register-prefetched TWO windows
-//     ahead; pooled / squared images are derived in LDS;
-//   * Flipout input signs are XOR masks on the B fragments (constant over the rows of a window);
-//   * jobs may split K across waves (block-2 k3/k5 branches have only one n-tile each): partial
-//     accumulators are reduced through LDS by the owning wave.
-// ==========================================================================================
+// one compute wave of the role-specialised conv forward: an (n-tile, k-step range) job; jobs may split K
+// across waves (block-2 k3/k5 branches have only one n-tile each): partial accumulators are reduced
+// through LDS by the owning wave
 struct FwdJob {
   signed char b, nt, ks0, ks1;   // branch (-1: none), n-tile, k-step range [ks0, ks1)
   signed char grp, owner, member, nmember;  // K-split reduction group (-1: none)
 };
 
-struct ConvFwdPlan {
-  int nsplit, has_pool, n_red_groups, pad_;
-  FwdJob job[CV_WAVES][2];
-};
-
-template <int EM, int KS, int MAXJ>
-__global__ __launch_bounds__(CV_THREADS) void conv_fwd_bf_kernel(const GroupArgs A, const ConvFwdPlan F) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool DUAL = (EM != EM_PLAIN);
-  constexpr bool LRT = (EM == EM_LRT);
-  constexpr int PU = 2;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const GroupDesc& G = A.g;
-  const int s = blockIdx.x / F.nsplit, split = blockIdx.x - s * F.nsplit;
-  const int L = G.L, B = A.cg.B;
-  const int cwp = G.in_cin_p, c8n = cwp >> 3;
-  const int RS = img_row_stride(cwp, true);
-  const int pbytes = (IMG_ROWS * RS * 2 + 15) & ~15;  // one plane
-  u16* im_hi = (u16*)smem;                  // direct hi | lo, pooled hi | lo, squares direct | pooled
-  u16* im_lo = (u16*)(smem + pbytes);
-  u16* im_sq = (u16*)(smem + 4 * pbytes);
-  float* red = (float*)(smem + 6 * pbytes);
-  {
-    const int total = (6 * pbytes) >> 2;
-    uint32_t* z = (uint32_t*)smem;
-    for (int k = tid; k < total; k += CV_THREADS) z[k] = 0u;
-  }
-  const TensorRef tin = A.t[G.in_t];
-  const u16* g_hi = (const u16*)tin.p;
-  const u16* g_lo = (const u16*)tin.lo;
-  const int nu = L * c8n;  // 16-byte units per plane
-
-  // ---- jobs + weights -> registers ----
-  const int i16 = lane & 15, g4 = lane >> 4;
-  bf16x8 w_hi[MAXJ][KS], w_lo[MAXJ][KS], w_b[MAXJ][KS];
-  int boff[MAXJ][KS];       // LDS element offset of the lane's B fragment (mt = 0), incl. image select
-  int c8of[MAXJ][KS];       // channel group (for the sign masks)
-  int j_b[MAXJ], j_nt[MAXJ], j_nks[MAXJ], j_grp[MAXJ], j_owner[MAXJ], j_member[MAXJ], j_nmem[MAXJ];
-  // epilogue data of the job, hoisted out of the window loop (no dependent global loads per window)
-  f32x4 e_ba[MAXJ], e_bb[MAXJ];          // bias (mean | sampled) and LRT bias variance of the lane's 4 channels
-  int e_nv[MAXJ], e_ooff[MAXJ], e_octot[MAXJ], e_relu[MAXJ], e_layer[MAXJ], e_lch[MAXJ], e_cout[MAXJ], e_c4n[MAXJ];
-  u16* e_ohi[MAXJ]; u16* e_olo[MAXJ]; u16* e_q[MAXJ];
-#pragma unroll
-  for (int j = 0; j < MAXJ; ++j) {
-    const FwdJob J = F.job[wave][j];
-    j_b[j] = J.b;
-    j_nt[j] = J.nt;
-    j_nks[j] = J.b >= 0 ? (J.ks1 - J.ks0) : 0;
-    j_grp[j] = J.grp;
-    j_owner[j] = J.owner;
-    j_member[j] = J.member;
-    j_nmem[j] = J.nmember;
-    e_ba[j] = e_bb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    e_nv[j] = e_ooff[j] = e_octot[j] = e_relu[j] = e_layer[j] = e_lch[j] = e_cout[j] = e_c4n[j] = 0;
-    e_ohi[j] = e_olo[j] = e_q[j] = nullptr;
-    if (J.b >= 0) {
-      const BranchDesc& br = G.br[J.b];
-      const LayerDesc& ly = A.layers[br.layer];
-      const int chb = J.nt * 16 + 4 * g4;
-      e_nv[j] = br.cout - chb;  // <= 0: this lane has no real channel
-      const float* ba = A.ws.bias_a + (long)A.ws.bias_stride_a * s + ly.bias_off + br.n_off + chb;
-      const float* bb = A.ws.bias_b + ly.bias_off + br.n_off + chb;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (r < e_nv[j]) {
-          e_ba[j][r] = ba[r];
-          if constexpr (LRT) e_bb[j][r] = bb[r];
-        }
-      const TensorRef tout = A.t[br.out_t];
-      e_ohi[j] = (u16*)tout.p;
-      e_olo[j] = (u16*)tout.lo;
-      e_q[j] = (u16*)A.t[br.q_t].p;
-      e_octot[j] = tout.ctot;
-      e_ooff[j] = br.out_off + chb;
-      e_relu[j] = br.relu;
-      e_layer[j] = br.layer;
-      e_lch[j] = br.n_off + chb;
-      e_cout[j] = ly.cout;
-      e_c4n[j] = ly.cout_p16 >> 2;
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      w_hi[j][ks] = w_lo[j][ks] = w_b[j][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      boff[j][ks] = 0;
-      c8of[j][ks] = 0;
-      if (ks < j_nks[j]) {
-        const BranchDesc& br = G.br[J.b];
-        const LayerDesc& ly = A.layers[br.layer];
-        const int G8 = br.cin_p >> 3;
-        const int gg = (J.ks0 + ks) * 4 + g4;
-        const int tap = gg / G8, c8 = gg - tap * G8;
-        const bool valid = tap < ly.taps;
-        const long wo = (long)(br.n_off + J.nt * 16 + i16) * ly.KP + (long)(J.ks0 + ks) * 32 + g4 * 8;
-        const long sa = A.ws.slot_stride_a * s, sb = A.ws.slot_stride_b * s;
-        w_hi[j][ks] = *(const bf16x8*)((const u16*)A.ws.a_hi + sa + ly.w_off + wo);
-        w_lo[j][ks] = *(const bf16x8*)((const u16*)A.ws.a_lo + sa + ly.w_off + wo);
-        if constexpr (DUAL) w_b[j][ks] = *(const bf16x8*)((const u16*)A.ws.b + sb + ly.w_off + wo);
-        boff[j][ks] = valid ? ((br.pool ? pbytes : 0) + (tap - ly.pad + HALO) * RS + br.in_off + c8 * 8) : 0;
-        c8of[j][ks] = valid ? c8 : 0;
-      }
-    }
-  }
-  // job 1 may reuse job 0's B fragments (same image, channels, taps and k-range)
-  bool same_b = false;
-  if (MAXJ > 1 && j_b[0] >= 0 && j_b[MAXJ - 1] >= 0) {
-    const BranchDesc& b0 = G.br[j_b[0]];
-    const BranchDesc& b1 = G.br[j_b[MAXJ - 1]];
-    const FwdJob J0 = F.job[wave][0], J1 = F.job[wave][MAXJ - 1];
-    same_b = b0.pool == b1.pool && b0.in_off == b1.in_off && b0.cin_p == b1.cin_p &&
-             A.layers[b0.layer].taps == A.layers[b1.layer].taps && J0.ks0 == J1.ks0 && J0.ks1 == J1.ks1;
-  }
-
-  // ---- staging plan: unit U = tid + 512*u over [hi plane | lo plane] ----
-  int st_src[PU], st_dst[PU];
-  bool st_lo[PU], st_ok[PU];
-#pragma unroll
-  for (int u = 0; u < PU; ++u) {
-    const int U = tid + u * CV_THREADS;
-    st_ok[u] = U < 2 * nu;
-    st_lo[u] = U >= nu;
-    const int r = st_lo[u] ? U - nu : U;
-    const int row = r / c8n, c8 = r - row * c8n;
-    st_src[u] = row * tin.ctot + c8 * 8;
-    st_dst[u] = (st_lo[u] ? (pbytes >> 1) : 0) + (row + HALO) * RS + c8 * 8;
-  }
-  uint4 pre0[PU], pre1[PU];
-  uint32_t sg0[MAXJ][4], sg1[MAXJ][4], so0[MAXJ], so1[MAXJ];  // flipout sign words (in: <=128 bits, out: 1 word)
-  auto prefetch = [&](int wl, uint4 (&pre)[PU], uint32_t (&sg)[MAXJ][4], uint32_t (&so)[MAXJ]) {
-    const long row0 = (long)(G.in_bcast ? wl : s * B + wl) * L * tin.ctot;
-#pragma unroll
-    for (int u = 0; u < PU; ++u) {
-      pre[u] = make_uint4(0, 0, 0, 0);
-      if (st_ok[u]) pre[u] = *(const uint4*)((st_lo[u] ? g_lo : g_hi) + row0 + st_src[u]);
-    }
-    if constexpr (EM == EM_FLIPOUT) {
-      const long ex = (long)s * B + wl;
-#pragma unroll
-      for (int j = 0; j < MAXJ; ++j) {
-        sg[j][0] = sg[j][1] = sg[j][2] = sg[j][3] = 0u;
-        so[j] = 0u;
-        if (j_b[j] >= 0) {
-          const BranchDesc& br = G.br[j_b[j]];
-          const LayerDesc& ly = A.layers[br.layer];
-          const uint32_t* pi = A.nz.sign_in + ly.sign_in_off * A.nz.examples + ex * ly.sign_in_words;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            if (k < ly.sign_in_words) sg[j][k] = pi[k];
-          const int nbit = br.n_off + j_nt[j] * 16;
-          so[j] = A.nz.sign_out[ly.sign_out_off * A.nz.examples + ex * ly.sign_out_words + (nbit >> 5)] >> (nbit & 31);
-        }
-      }
-    }
-  };
-
-  auto step = [&](int wl, uint4 (&pre)[PU], uint32_t (&sg)[MAXJ][4], uint32_t (&so)[MAXJ], int wl_next2) {
-    __syncthreads();  // images of the previous window are no longer read
-#pragma unroll
-    for (int u = 0; u < PU; ++u)
-      if (st_ok[u]) *(uint4*)&im_hi[st_dst[u]] = pre[u];
-    // flipout: keep this window's sign words (the prefetch below reuses the registers)
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    uint32_t sgc[MAXJ][4], so_w[MAXJ];
-    if constexpr (EM == EM_FLIPOUT) {
-#pragma unroll
-      for (int j = 0; j < MAXJ; ++j) {
-        so_w[j] = so[j];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sgc[j][k] = sg[j][k];
-      }
-    }
-    __syncthreads();
-    if (wl_next2 >= 0) prefetch(wl_next2, pre, sg, so);  // lands two windows later
-    if (F.has_pool || LRT) {
-      for (int U = tid; U < nu; U += CV_THREADS) {
-        const int row = U / c8n, c8 = U - row * c8n;
-        const int o = (row + HALO) * RS + c8 * 8;
-        const uint4 h0 = *(const uint4*)&im_hi[o], l0 = *(const uint4*)&im_lo[o];
-        const uint32_t hh[4] = {h0.x, h0.y, h0.z, h0.w}, ll[4] = {l0.x, l0.y, l0.z, l0.w};
-        uint32_t ph[4], pl[4], sq[4], psq[4];
-        uint32_t ha[4] = {0, 0, 0, 0}, la[4] = {0, 0, 0, 0}, hb[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0};
-        const bool up = row > 0, dn = row + 1 < L;
-        if (F.has_pool) {
-          if (up) {
-            const uint4 a = *(const uint4*)&im_hi[o - RS], b = *(const uint4*)&im_lo[o - RS];
-            ha[0] = a.x; ha[1] = a.y; ha[2] = a.z; ha[3] = a.w;
-            la[0] = b.x; la[1] = b.y; la[2] = b.z; la[3] = b.w;
-          }
-          if (dn) {
-            const uint4 a = *(const uint4*)&im_hi[o + RS], b = *(const uint4*)&im_lo[o + RS];
-            hb[0] = a.x; hb[1] = a.y; hb[2] = a.z; hb[3] = a.w;
-            lb[0] = b.x; lb[1] = b.y; lb[2] = b.z; lb[3] = b.w;
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          uint32_t oh = 0, ol = 0, os = 0, ops = 0;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const int sh = 16 * e;
-            const u16 h = (u16)(hh[k] >> sh), l = (u16)(ll[k] >> sh);
-            u16 bh_ = h, bl_ = l;
-            if (F.has_pool) {
-              float best = bf2f(h) + bf2f(l);
-              if (up) {
-                const u16 h2 = (u16)(ha[k] >> sh), l2 = (u16)(la[k] >> sh);
-                const float v = bf2f(h2) + bf2f(l2);
-                if (v > best) { best = v; bh_ = h2; bl_ = l2; }
-              }
-              if (dn) {
-                const u16 h2 = (u16)(hb[k] >> sh), l2 = (u16)(lb[k] >> sh);
-                const float v = bf2f(h2) + bf2f(l2);
-                if (v > best) { best = v; bh_ = h2; bl_ = l2; }
-              }
-            }
-            oh |= (uint32_t)bh_ << sh;
-            ol |= (uint32_t)bl_ << sh;
-            if constexpr (LRT) {
-              const float x = bf2f(h), xp = bf2f(bh_);
-              os |= (uint32_t)f2bf(x * x) << sh;
-              ops |= (uint32_t)f2bf(xp * xp) << sh;
-            }
-          }
-          ph[k] = oh; pl[k] = ol; sq[k] = os; psq[k] = ops;
-        }
-        if (F.has_pool) {
-          *(uint4*)&im_hi[(pbytes) + o] = make_uint4(ph[0], ph[1], ph[2], ph[3]);        // pooled hi  (plane 2)
-          *(uint4*)&im_hi[(pbytes) + (pbytes >> 1) + o] = make_uint4(pl[0], pl[1], pl[2], pl[3]);  // pooled lo (plane 3)
-        }
-        if constexpr (LRT) {
-          *(uint4*)&im_sq[o] = make_uint4(sq[0], sq[1], sq[2], sq[3]);
-          if (F.has_pool) *(uint4*)&im_sq[(pbytes >> 1) + o] = make_uint4(psq[0], psq[1], psq[2], psq[3]);
-        }
-      }
-      __syncthreads();
-    }
-    // ---------------- MFMA ----------------
-    f32x4 acc_a[MAXJ][2], acc_b[MAXJ][2];
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        acc_a[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc_b[j][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    bf16x8 bh[2], bl[2], b2[2];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-      for (int j = 0; j < MAXJ; ++j) {
-        if (ks < j_nks[j]) {
-          if (j == 0 || !same_b) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-              const int o = boff[j][ks] + (mt * 16 + i16) * RS;
-              bh[mt] = *(const bf16x8*)&im_hi[o];
-              bl[mt] = *(const bf16x8*)&im_lo[o];
-              if constexpr (LRT) b2[mt] = *(const bf16x8*)&im_sq[(o >= pbytes ? o - pbytes + (pbytes >> 1) : o)];
-            }
-          }
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            acc_a[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[j][ks], bh[mt], acc_a[j][mt], 0, 0, 0);
-            acc_a[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[j][ks], bl[mt], acc_a[j][mt], 0, 0, 0);
-            acc_a[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[j][ks], bh[mt], acc_a[j][mt], 0, 0, 0);
-            if constexpr (LRT) {
-              acc_b[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[j][ks], b2[mt], acc_b[j][mt], 0, 0, 0);
-            } else if constexpr (EM == EM_FLIPOUT) {
-              // XOR mask of the lane's 8 channels: sign bit of each bf16 (constant over rows)
-              const int c8 = c8of[j][ks];
-              const int wi = c8 >> 2;
-              const uint32_t word = wi == 0 ? sgc[j][0] : (wi == 1 ? sgc[j][1] : (wi == 2 ? sgc[j][2] : sgc[j][3]));
-              const uint32_t byte = (word >> ((c8 & 3) * 8)) & 0xffu;
-              u32x4 fm;
-#pragma unroll
-              for (int k = 0; k < 4; ++k)
-                fm[k] = (((byte >> (2 * k)) & 1u) << 15) | (((byte >> (2 * k + 1)) & 1u) << 31);
-              const u32x4 xb = __builtin_bit_cast(u32x4, bh[mt]) ^ fm;
-              acc_b[j][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[j][ks], __builtin_bit_cast(bf16x8, xb),
-                                                                     acc_b[j][mt], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-    // ---------------- K-split reduction ----------------
-    if (F.n_red_groups > 0) {
-      if (j_b[0] >= 0 && j_grp[0] >= 0) {
-        float* r = red + (size_t)wave * (2 * 2 * 256);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          *(f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4] = acc_a[0][mt];
-          if constexpr (DUAL) *(f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4] = acc_b[0][mt];
-        }
-      }
-      __syncthreads();
-      if (j_b[0] >= 0 && j_grp[0] >= 0 && j_owner[0]) {
-        // members of a group are consecutive waves starting at the owner
-        for (int m = 1; m < j_nmem[0]; ++m) {
-          const float* r = red + (size_t)(wave + m) * (2 * 2 * 256);
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const f32x4 pa = *(const f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc_a[0][mt][k] += pa[k];
-            if constexpr (DUAL) {
-              const f32x4 pb = *(const f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4];
-#pragma unroll
-              for (int k = 0; k < 4; ++k) acc_b[0][mt][k] += pb[k];
-            }
-          }
-        }
-      }
-    }
-    // ---------------- epilogue ----------------
-    const int w = s * B + wl;
-#pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-      if (j_b[j] < 0 || e_nv[j] <= 0) continue;
-      if (j_grp[j] >= 0 && !j_owner[j]) continue;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int row = mt * 16 + i16;
-        if (row >= L) continue;
-        const int R = w * L + row;
-        f32x4 v = acc_a[j][mt];
-        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (LRT) {
-          f32x4 eps;
-          if (A.nz.use_philox_lrt) {
-            const long Rg = global_row(A.cg, L, R);
-            const uint64_t idx = (uint64_t)Rg * (uint64_t)e_c4n[j] + (uint64_t)(e_lch[j] >> 2);
-            eps = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)e_layer[j] << 8), A.nz.step,
-                                 A.nz.seed);
-          } else {
-            const float* e = A.nz.lrt_eps[e_layer[j]] + (long)R * e_cout[j] + e_lch[j];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) eps[r] = (r < e_nv[j]) ? e[r] : 0.f;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float loc = v[r] + e_ba[j][r];
-            float var = acc_b[j][mt][r] + e_bb[j][r];
-            if (var < 0.f) var = 1e-6f;
-            const float sd = sqrtf(var);
-            v[r] = loc + sd * eps[r];
-            qv[r] = sd > 0.f ? eps[r] / (2.f * sd) : 0.f;
-          }
-        } else if constexpr (EM == EM_FLIPOUT) {
-          const uint32_t bits = so_w[j] >> (4 * g4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pb = acc_b[j][mt][r];
-            v[r] = v[r] + e_ba[j][r] + (((bits >> r) & 1u) ? -pb : pb);
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += e_ba[j][r];
-        }
-        if (e_relu[j]) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        const long oo = (long)R * e_octot[j] + e_ooff[j];
-        u16 h[4], l[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h[r] = f2bf(v[r]);
-          l[r] = f2bf(v[r] - bf2f(h[r]));
-        }
-        if (e_nv[j] >= 4) {
-          *(uint2*)(e_ohi[j] + oo) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-          *(uint2*)(e_olo[j] + oo) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
-          if constexpr (LRT) *(uint2*)(e_q[j] + oo) = pack_bf4(qv);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < e_nv[j]) {
-              e_ohi[j][oo + r] = h[r];
-              e_olo[j][oo + r] = l[r];
-              if constexpr (LRT) e_q[j][oo + r] = f2bf(qv[r]);
-            }
-        }
-      }
-    }
-  };
-
-  const int pp = B;
-  int wl = split;
-  if (wl < pp) prefetch(wl, pre0, sg0, so0);
-  if (wl + F.nsplit < pp) prefetch(wl + F.nsplit, pre1, sg1, so1);
-  for (; wl < pp; wl += 2 * F.nsplit) {
-    const int n2 = wl + 2 * F.nsplit, n3 = wl + 3 * F.nsplit;
-    step(wl, pre0, sg0, so0, n2 < pp ? n2 : -1);
-    if (wl + F.nsplit < pp) step(wl + F.nsplit, pre1, sg1, so1, n3 < pp ? n3 : -1);
-  }
-}
-
-
-// x [rows][F] fp32 -> bf16 hi/lo planes [rows][CP] (zero padded channels); once per call
+// bf16 hi/lo planes [rows][CP] of the raw fp32 windows (channel pads zero)
 __global__ void x_planes_kernel(const float* x, u16* hi, u16* lo, long rows, int F, int CP) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * CP) return;
@@ -813,7 +119,7 @@ __device__ __forceinline__ void build_sign_lut(uint4* lut, int tid, int nthreads
 // diagnostics only (GroupArgs::dbg, null in production): lane 0 of every wave of workgroup 0 records
 // s_memtime at phase `ph` of window iteration `k`
 #define BNN_STAMP_DECL(A)                                                                                   \
-  const bool stamp_on = (A).dbg != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;                   \
+  const bool stamp_on = (A).dbg != nullptr && blockIdx.x == (unsigned)(A).dbg_block && (threadIdx.x & 63) == 0;                   \
   const int stamp_wave = threadIdx.x >> 6;                                                                  \
   auto stamp = [&](int k, int ph) {                                                                         \
     if (stamp_on && k < 48) (A).dbg[((size_t)stamp_wave * 48 + k) * 8 + ph] = __builtin_amdgcn_s_memtime(); \
@@ -1290,653 +596,12 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
   }
 }
 
-// ==========================================================================================
-// conv_dx_dma_kernel : gradient w.r.t. the input tensor of a conv group (or its pooled copy),
-// same role-specialised structure as conv_fwd_dma_kernel.
-//   loaders : DMA the dY / Y(hi) [/ q] channel slices of every selected branch (one dense,
-//             XOR-swizzled sub-image per branch and plane type) + the X hi plane for LRT, two
-//             windows ahead; every DMA instruction serves ONE (plane type, branch), so its source
-//             base is wave-uniform and the loader loop contains no ordinary load;
-//   all     : dz = dY * [Y > 0]   (LRT: dz2 = dz * q)  in LDS;
-//   compute : job = one 16-channel tile of the input tensor; K runs over the selected branches
-//             (transposed + flipped weight images, fragments in registers);
-//             dX = Wa^T dz + { LRT: 2 X (Wb^T dz2) | Flipout: s_in_b (Wb_b^T (dz s_out_b)) }.
-// ==========================================================================================
-enum { DX_KS = 5, DX_MAXB = 3, DX_MAXI = 40, DX_NC = 8, DX_THREADS = (DX_NC + FW_NL) * 64 };  // 12 waves: 170 VGPRs each
-
-struct DxInst {
-  signed char pt, b;     // plane type (0 dY, 1 Y, 2 q, 3 X) and branch
-  short q0;              // first 16-byte chunk of this instruction inside the sub-image
-};
-
-struct ConvDxPlan {
-  int nsplit, nks, ntile, pool_sel;
-  int zbase[BNN_MAX_BRANCH];      // element offset of branch b's sub-image inside a plane (-1: not selected)
-  int zelems;                     // elements of one plane (all sub-images, incl. halo rows)
-  int ninst;
-  signed char ks_b[DX_KS], ks_i[DX_KS], ks_slot[DX_KS], pad_;
-  DxInst inst[DX_MAXI];
-};
-
-
 // chunk position of channel chunk c8 in image row r of a dense image with cb8 chunks per row
 __device__ __forceinline__ int swz(int c8, int r, int cb8) {
   return c8 ^ ((cb8 >= 16 ? r : (r / (16 / cb8))) & (cb8 - 1));
 }
 
-template <int EM>
-__global__ __launch_bounds__(DX_THREADS) void conv_dx_dma_kernel(const GroupArgs A, const ConvDxPlan D) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool DUAL = (EM != EM_PLAIN);
-  constexpr bool LRT = (EM == EM_LRT);
-  constexpr int NPT = LRT ? 3 : 2;              // plane types per branch: dY, Y [, q]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const GroupDesc& G = A.g;
-  const int s = blockIdx.x / D.nsplit, split = blockIdx.x - s * D.nsplit;
-  const int L = G.L, B = A.cg.B;
-  const int zbytes = D.zelems * 2;
-  const int xw = G.in_cin_p, x8n = xw >> 3;
-  const int xbytes = LRT ? IMG_ROWS * xw * 2 : 0;
-  const int slot_bytes = NPT * zbytes + xbytes;
-  // LDS: raw[FW_SLOTS][dY | Y | q | X] | dz | dz2 | sign words
-  u16* dzi = (u16*)(smem + FW_SLOTS * slot_bytes);
-  u16* dz2 = (u16*)(smem + FW_SLOTS * slot_bytes + zbytes);
-  uint32_t* sgn = (uint32_t*)(smem + FW_SLOTS * slot_bytes + 2 * zbytes);
-  {
-    const int total = (FW_SLOTS * slot_bytes + 2 * zbytes + FW_SLOTS * 64 * 4) >> 2;
-    uint32_t* z = (uint32_t*)smem;
-    for (int k = tid; k < total; k += DX_THREADS) z[k] = 0u;
-  }
-  const TensorRef tin = A.t[G.in_t];
-  const bool is_loader = wave >= DX_NC;
-  const int lw = wave - DX_NC;
-  const int my_ninst = is_loader ? max(0, (D.ninst - lw + FW_NL - 1) / FW_NL) : 0;
-  const int nwin = (B - split + D.nsplit - 1) / D.nsplit;
-  auto win_of = [&](int k) { return split + k * D.nsplit; };
-
-  int dx_t = -1;
-  for (int b = 0; b < G.n_branch; ++b)
-    if (D.zbase[b] >= 0) dx_t = G.br[b].dx_t;
-  const TensorRef tdx = A.t[dx_t];
-
-  // flipout sign words: [branch][8] = 4 words sign_in + 2 words sign_out (loader 0)
-  const uint32_t* sg_src = nullptr;
-  long sg_stride = 0;
-  bool sg_ok = false;
-  if (EM == EM_FLIPOUT && is_loader && lw == 0 && lane < 8 * G.n_branch) {
-    const int b = lane >> 3, k = lane & 7;
-    const BranchDesc& br = G.br[b];
-    const LayerDesc& ly = A.layers[br.layer];
-    if (k < 4 && k < ly.sign_in_words) {
-      sg_src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + k;
-      sg_stride = ly.sign_in_words;
-      sg_ok = true;
-    } else if (k >= 4 && k - 4 < ly.sign_out_words && k < 6) {
-      sg_src = A.nz.sign_out + ly.sign_out_off * A.nz.examples + (k - 4);
-      sg_stride = ly.sign_out_words;
-      sg_ok = true;
-    }
-  }
-  // everything about an instruction except the lane part is wave-uniform (scalar loads of the
-  // kernel arguments): no vector load in the loader loop
-  auto issue = [&](int k) {
-    const int wl = win_of(k);
-    const long w = (long)s * B + wl;
-    char* slot = smem + (k % FW_SLOTS) * slot_bytes;
-    int lane_o = lane;
-    asm volatile("" : "+v"(lane_o));
-    for (int i = 0; i < my_ninst; ++i) {
-      const DxInst I = D.inst[lw + i * FW_NL];
-      const int q = I.q0 + lane_o;
-      if (I.pt < 3) {
-        const BranchDesc& br = G.br[I.b];
-        const int cb8 = br.cout >> 3;
-        const int row = q / cb8, p = q - row * cb8;
-        const int c8 = swz(p, row + HALO, cb8);
-        const TensorRef tt = I.pt == 0 ? A.t[br.out_t + T_GRAD] : (I.pt == 1 ? A.t[br.out_t] : A.t[br.q_t]);
-        const u16* src = (const u16*)tt.p + (w * L + row) * tt.ctot + br.out_off + c8 * 8;
-        char* dst = slot + I.pt * zbytes + (D.zbase[I.b] + HALO * br.cout) * 2 + I.q0 * 16;
-        if (q < L * cb8) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
-      } else {
-        const int row = q / x8n, p = q - row * x8n;
-        const int c8 = swz(p, row + HALO, x8n);
-        const u16* src = (const u16*)tin.p + (w * L + row) * tin.ctot + c8 * 8;
-        char* dst = slot + NPT * zbytes + HALO * xw * 2 + I.q0 * 16;
-        if (q < L * x8n) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
-      }
-    }
-    if (EM == EM_FLIPOUT && lw == 0) {
-      if (sg_ok) dma4(sg_src + w * sg_stride, __builtin_amdgcn_readfirstlane(lds_addr(sgn + (k % FW_SLOTS) * 64)));
-    }
-  };
-  const int n_issue = my_ninst + ((EM == EM_FLIPOUT && lw == 0) ? 1 : 0);  // every instruction has active lanes
-
-  // =========================== compute state ===========================
-  const int i16 = lane & 15, g4 = lane >> 4;
-  bf16x8 w_a[DX_KS], w_b[DX_KS];
-  int k_pk[DX_KS];      // per lane: image row base (tap - pad + HALO) | channel chunk inside the branch << 8
-  bool k_on[DX_KS];     // wave-uniform: this k-step exists for this tile
-  const int ct = wave;  // compute wave w owns input-channel tile w
-  const bool has_job = !is_loader && ct < D.ntile;
-  int k_cb8[DX_KS], k_zb[DX_KS], k_slot[DX_KS], k_noff[DX_KS], k_bb[DX_KS];   // wave-uniform
-#pragma unroll
-  for (int ks = 0; ks < DX_KS; ++ks) {
-    w_a[ks] = w_b[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    k_on[ks] = false;
-    k_pk[ks] = HALO;
-    k_cb8[ks] = 1; k_zb[ks] = 0; k_slot[ks] = 0; k_noff[ks] = 0; k_bb[ks] = 0;
-    if (has_job && ks < D.nks) {
-      const int b = D.ks_b[ks];
-      const BranchDesc& br = G.br[b];
-      const LayerDesc& ly = A.layers[br.layer];
-      const int c0 = ct * 16 - br.in_off;                 // first layer-input channel of this tile
-      if (c0 >= 0 && c0 < br.cin_p) {
-        k_on[ks] = true;
-        const int G8 = ly.cout_p8 >> 3;                   // K groups per tap in the transposed image
-        const int gg = D.ks_i[ks] * 4 + g4;
-        const int tap = gg / G8, c8 = gg - tap * G8;
-        const bool valid = tap < ly.taps && c8 * 8 < br.cout;
-        const long wo = (long)(c0 + i16) * ly.KPt + (long)D.ks_i[ks] * 32 + g4 * 8;
-        const long sa = A.ws.slott_stride_a * s, sb = A.ws.slott_stride_b * s;
-        if (valid) {
-          w_a[ks] = *(const bf16x8*)((const u16*)A.ws.at + sa + ly.wt_off + wo);
-          if constexpr (DUAL) w_b[ks] = *(const bf16x8*)((const u16*)A.ws.bt + sb + ly.wt_off + wo);
-        }
-        k_pk[ks] = valid ? ((tap - ly.pad + HALO) | (c8 << 8)) : HALO;   // per lane (tap depends on g4)
-        k_cb8[ks] = br.cout >> 3;
-        k_zb[ks] = D.zbase[b];
-        k_slot[ks] = D.ks_slot[ks];
-        k_noff[ks] = br.n_off;
-        k_bb[ks] = b;
-      }
-    }
-  }
-  // flipout: per selected branch, the sign_in bits of this tile's 16 channels
-  int fo_branch[DX_MAXB], fo_c0[DX_MAXB];
-#pragma unroll
-  for (int q = 0; q < DX_MAXB; ++q) {
-    fo_branch[q] = -1;
-    fo_c0[q] = 0;
-  }
-  if (EM == EM_FLIPOUT && has_job) {
-    int q = 0;
-    for (int b = 0; b < G.n_branch; ++b)
-      if (D.zbase[b] >= 0 && q < DX_MAXB) {
-        const int c0 = ct * 16 - G.br[b].in_off;
-        if (c0 >= 0 && c0 < G.br[b].cin_p) {
-          fo_branch[q] = b;
-          fo_c0[q] = c0;
-        }
-        ++q;
-      }
-  }
-  const int och = ct * 16 + 4 * g4;   // channel of the target tensor held by this lane
-  const bool pool_x = D.pool_sel != 0;
-
-  // ---- mask pass plan: one 16-byte chunk per thread and pass (fixed per thread) ----
-  // unit U -> (branch, row, chunk): walk the selected branches
-  int m_o = -1, m_relu = 0;
-  {
-    int U = tid;
-    for (int b = 0; b < G.n_branch; ++b) {
-      if (D.zbase[b] < 0) continue;
-      const int cb8 = G.br[b].cout >> 3;
-      const int n = L * cb8;
-      if (U >= 0 && U < n) {
-        const int row = U / cb8, p = U - row * cb8;
-        m_o = D.zbase[b] + (row + HALO) * G.br[b].cout + p * 8;   // same position in dY / Y / q / dz images
-        m_relu = G.br[b].relu;
-        U = -1;
-      } else if (U >= n) {
-        U -= n;
-      }
-    }
-  }
-
-  __syncthreads();
-  if (is_loader) {
-    if (nwin > 0) issue(0);
-    if (nwin > 1) issue(1);
-  }
-
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  BNN_STAMP_DECL(A);
-  for (int k = 0; k < nwin; ++k) {
-    stamp(k, 0);
-    const int slotk = k % FW_SLOTS;
-    const u16* r_dy = (const u16*)(smem + slotk * slot_bytes);
-    const u16* r_y = r_dy + (zbytes >> 1);
-    const u16* r_q = r_dy + zbytes;
-    const u16* r_x = (const u16*)(smem + slotk * slot_bytes + NPT * zbytes);
-    if (is_loader) {
-      if (k + 1 < nwin) BNN_WAIT_VMCNT(n_issue);
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    stamp(k, 1);
-    lds_barrier();   // B1
-    stamp(k, 2);
-    // ---- dz = dY * [Y > 0] (, dz2 = dz * q) ----
-    if (m_o >= 0) {
-      uint4 g = *(const uint4*)&r_dy[m_o];
-      if (m_relu) {
-        const uint4 y = *(const uint4*)&r_y[m_o];
-        auto msk = [](uint32_t yy) {   // bf16 > 0  <=>  sign bit clear and not zero
-          const uint32_t lo = ((yy & 0x8000u) == 0 && (yy & 0x7fffu) != 0) ? 0xffffu : 0u;
-          const uint32_t hi = ((yy & 0x80000000u) == 0 && (yy & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
-          return lo | hi;
-        };
-        g.x &= msk(y.x); g.y &= msk(y.y); g.z &= msk(y.z); g.w &= msk(y.w);
-      }
-      *(uint4*)&dzi[m_o] = g;
-      if constexpr (LRT) {
-        const uint4 qq = *(const uint4*)&r_q[m_o];
-        const uint32_t gg[4] = {g.x, g.y, g.z, g.w}, qv[4] = {qq.x, qq.y, qq.z, qq.w};
-        uint32_t out[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a0 = bf2f((u16)(gg[e] & 0xffff)) * bf2f((u16)(qv[e] & 0xffff));
-          const float a1 = bf2f((u16)(gg[e] >> 16)) * bf2f((u16)(qv[e] >> 16));
-          out[e] = (uint32_t)f2bf(a0) | ((uint32_t)f2bf(a1) << 16);
-        }
-        *(uint4*)&dz2[m_o] = make_uint4(out[0], out[1], out[2], out[3]);
-      }
-    }
-    stamp(k, 3);
-    lds_barrier();   // B2
-    stamp(k, 4);
-    if (is_loader) {
-      if (k + 2 < nwin) issue(k + 2);
-      stamp(k, 5);
-    }
-    // ---------------- MFMA ----------------
-    if (has_job) {
-      f32x4 acc_a[2], acc_b[DX_MAXB][2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        acc_a[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < DX_MAXB; ++q) acc_b[q][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      const uint32_t* sg = sgn + slotk * 64;
-#pragma unroll
-      for (int ks = 0; ks < DX_KS; ++ks) {
-        if (k_on[ks]) {
-          u32x4 fm = {0u, 0u, 0u, 0u};
-          if constexpr (EM == EM_FLIPOUT) {
-            // sign_out of the 8 couts of this lane group
-            const int n0 = k_noff[ks] + ((k_pk[ks] >> 8) & 0xff) * 8;
-            const uint32_t byte = (sg[k_bb[ks] * 8 + 4 + (n0 >> 5)] >> (n0 & 31)) & 0xffu;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              fm[q] = (((byte >> (2 * q)) & 1u) << 15) | (((byte >> (2 * q + 1)) & 1u) << 31);
-          }
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const int rr = (k_pk[ks] & 0xff) + mt * 16 + i16;
-            const int o = k_zb[ks] + rr * (k_cb8[ks] * 8) + swz((k_pk[ks] >> 8) & 0xff, rr, k_cb8[ks]) * 8;
-            const bf16x8 bz = *(const bf16x8*)&dzi[o];
-            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_a[ks], bz, acc_a[mt], 0, 0, 0);
-            if constexpr (LRT) {
-              const bf16x8 b2 = *(const bf16x8*)&dz2[o];
-              acc_b[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], b2, acc_b[0][mt], 0, 0, 0);
-            } else if constexpr (EM == EM_FLIPOUT) {
-              const u32x4 xb = __builtin_bit_cast(u32x4, bz) ^ fm;
-#pragma unroll
-              for (int q = 0; q < DX_MAXB; ++q)
-                if (q == k_slot[ks])
-                  acc_b[q][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], __builtin_bit_cast(bf16x8, xb),
-                                                                        acc_b[q][mt], 0, 0, 0);
-            }
-          }
-        }
-      }
-      stamp(k, 5);
-      // ---------------- epilogue ----------------
-      const int wl = win_of(k);
-      const long w = (long)s * B + wl;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int row = mt * 16 + i16;
-        if (row >= L) continue;
-        f32x4 v = acc_a[mt];
-        if constexpr (LRT) {
-          // + 2 * X * (Wb^T dz2), X = bf16 input (pooled for the pooled branch); 4 channels = half a chunk
-          auto xat = [&](int r) {
-            const int ri = r + HALO;
-            return unpack_bf4(*(const uint2*)&r_x[ri * xw + swz(och >> 3, ri, x8n) * 8 + (och & 7)]);
-          };
-          f32x4 xv = xat(row);
-          if (pool_x) {
-            if (row > 0) {
-              const f32x4 a = xat(row - 1);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) xv[r] = fmaxf(xv[r], a[r]);
-            }
-            if (row + 1 < L) {
-              const f32x4 a = xat(row + 1);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) xv[r] = fmaxf(xv[r], a[r]);
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += 2.f * xv[r] * acc_b[0][mt][r];
-        } else if constexpr (EM == EM_FLIPOUT) {
-#pragma unroll
-          for (int q = 0; q < DX_MAXB; ++q) {
-            if (fo_branch[q] >= 0) {
-              const int cb = fo_c0[q] + 4 * g4;
-              const uint32_t bits = sg[fo_branch[q] * 8 + (cb >> 5)] >> (cb & 31);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += ((bits >> r) & 1u) ? -acc_b[q][mt][r] : acc_b[q][mt][r];
-            }
-          }
-        }
-        *(uint2*)((u16*)tdx.p + (w * L + row) * tdx.ctot + och) = pack_bf4(v);
-      }
-    }
-    stamp(k, 6);
-  }
-}
-
-// ==========================================================================================
-// dense_fwd_dma_kernel : variational forward of a dense (Linear) layer, bf16 planes.
-// One workgroup = one 32-row window of example rows (one particle); the K dimension is walked in
-// 128-channel chunks that the loader waves stream with LDS-DMA two chunks ahead.  Compute wave
-// (nt, m) owns n-tile nt and the chunks c = m (mod members): after its MFMAs on chunk c it
-// issues the weight-fragment loads of chunk c + members into the same registers, so they have
-// `members` iterations to arrive.  Partial sums of the members are reduced through LDS once per
-// window; Flipout input signs are per example ROW here (XOR masks per lane).
-// ==========================================================================================
-enum { DN_CH = 128, DN_ROWS = 32 };
-
-struct DenseFwdPlan {
-  int ntile;      // n-tiles of the branch (cout / 16)
-  int members;    // compute waves per n-tile
-  int nchunk;
-  int pad_;
-};
-
-template <int EM>
-__global__ __launch_bounds__(FW_THREADS) void dense_fwd_dma_kernel(const GroupArgs A, const DenseFwdPlan F) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool DUAL = (EM != EM_PLAIN);
-  constexpr bool LRT = (EM == EM_LRT);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const GroupDesc& G = A.g;
-  const BranchDesc& br = G.br[0];
-  const LayerDesc& ly = A.layers[br.layer];
-  const Win W = decode_win(G, A.cg, blockIdx.x);
-  const int s = W.s;
-  const int pbytes = DN_ROWS * DN_CH * 2;              // one plane of a chunk (dense rows, 256 B)
-  // LDS: raw[FW_SLOTS][hi | lo] | sq | sign words [FW_SLOTS][32 rows][4] | red
-  u16* raw = (u16*)smem;
-  u16* sqi = (u16*)(smem + FW_SLOTS * 2 * pbytes);
-  uint32_t* sgn = (uint32_t*)(smem + (FW_SLOTS * 2 + 1) * pbytes);
-  float* red = (float*)(smem + (FW_SLOTS * 2 + 1) * pbytes + FW_SLOTS * 128 * 4);
-  {
-    const int total = ((FW_SLOTS * 2 + 1) * pbytes + FW_SLOTS * 128 * 4) >> 2;
-    uint32_t* z = (uint32_t*)smem;
-    for (int k = tid; k < total; k += FW_THREADS) z[k] = 0u;
-  }
-  const TensorRef tin = A.t[G.in_t];
-  const bool is_loader = wave >= FW_NC;
-  const int lw = wave - FW_NC;
-  const int nchunk = F.nchunk;
-  // =========================== loader waves: own code path ===========================
-  // 2 planes x 8 instructions (32 rows x 16 chunks of 16 B = 8 KB) per K-chunk, 4 per loader.  Every instruction
-  // keeps its per-lane source address in a VGPR pair that advances by one chunk (256 B) per issue; the
-  // lane predicate only differs in the last, partial chunk.  issue() is called for chunks 0, 1, 2, ...
-  if (is_loader) {
-    const char* a_src[4];
-    uint32_t a_dst[4];
-    uint32_t on_last = 0;
-    const int cw8_last = (br.cin_p - (nchunk - 1) * DN_CH) >> 3;   // valid 16-byte chunks per row of the last chunk
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int inst = lw + i * FW_NL;                 // 0..15: plane = inst >> 3
-      const int plane = inst >> 3, q0 = (inst & 7) * 64;
-      const int q = q0 + lane;
-      const int row = q >> 4, p = q & 15;
-      const int c8 = p ^ (row & 15);
-      // rows beyond the last valid one re-read that row: every instruction keeps active lanes
-      // (the counted vmcnt wait relies on it); their results are never stored
-      const int srow = min(row, W.nvalid - 1);
-      a_src[i] = (const char*)((const u16*)(plane ? tin.lo : tin.p) + (long)(W.in_row0 + srow) * tin.ctot + c8 * 8);
-      a_dst[i] = (uint32_t)(plane * pbytes + q0 * 16);
-      if (c8 < cw8_last) on_last |= 1u << i;
-    }
-    // flipout sign_in words of a chunk: lane -> (row, word): 128 lanes over loaders 0 and 1
-    const uint32_t* sg_src = nullptr;
-    int sg_n = 0;   // chunks for which this lane's word exists
-    if (EM == EM_FLIPOUT && lw < 2) {
-      const int q = lw * 64 + lane;
-      const int row = q >> 2, k = q & 3;
-      const int srow = min(row, W.nvalid - 1);
-      sg_src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + (long)(W.ex0 + srow) * ly.sign_in_words + k;
-      sg_n = (ly.sign_in_words - k + 3) >> 2;
-    }
-    asm volatile("" : "+v"(sg_src), "+v"(sg_n));   // loads consumed before the DMA sequence (no vmcnt wait inside it)
-    const uint32_t lds0 = lds_addr(smem);
-    auto issue = [&](int c) {
-      const uint32_t sbase = lds0 + (uint32_t)((c % FW_SLOTS) * 2 * pbytes);
-      const bool last = c == nchunk - 1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint32_t on = on_last;
-        asm volatile("" : "+v"(on));
-        if (!last || ((on >> i) & 1u)) dma16(a_src[i], __builtin_amdgcn_readfirstlane(sbase + a_dst[i]));
-        a_src[i] += DN_CH * 2;
-      }
-      if (EM == EM_FLIPOUT && lw < 2) {
-        if (c < sg_n) dma4(sg_src, lds0 + (uint32_t)((FW_SLOTS * 2 + 1) * pbytes + ((c % FW_SLOTS) * 128 + lw * 64) * 4));
-        sg_src += 4;
-      }
-    };
-    const int n_issue = 4 + ((EM == EM_FLIPOUT && lw < 2) ? 1 : 0);
-    __syncthreads();
-    BNN_STAMP_DECL(A);
-    if (nchunk > 0) issue(0);
-    if (nchunk > 1) issue(1);
-    for (int c = 0; c < nchunk; ++c) {
-      stamp(c, 0);
-      if (c + 1 < nchunk) BNN_WAIT_VMCNT(n_issue);
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      stamp(c, 1);
-      lds_barrier();   // B1
-      stamp(c, 2);
-      if constexpr (LRT) lds_barrier();  // B2
-      if (c + 2 < nchunk) issue(c + 2);
-      stamp(c, 3);
-    }
-    if (F.members > 1) lds_barrier();
-    return;
-  }
-
-  // =========================== compute state ===========================
-  const int i16 = lane & 15, g4 = lane >> 4;
-  const int nt = wave / F.members, mem = wave - nt * F.members;
-  const bool has_job = !is_loader && nt < F.ntile;
-  bf16x8 w_hi[4], w_lo[4], w_b[4];
-  const long sa = A.ws.slot_stride_a * s, sb = A.ws.slot_stride_b * s;
-  auto load_w = [&](int c) {
-    const int nks = min(DN_CH, br.cin_p - c * DN_CH) >> 5;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      w_hi[ks] = w_lo[ks] = w_b[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (ks < nks) {
-        const long wo = (long)(br.n_off + nt * 16 + i16) * ly.KP + (long)c * DN_CH + ks * 32 + g4 * 8;
-        w_hi[ks] = *(const bf16x8*)((const u16*)A.ws.a_hi + sa + ly.w_off + wo);
-        w_lo[ks] = *(const bf16x8*)((const u16*)A.ws.a_lo + sa + ly.w_off + wo);
-        if constexpr (DUAL) w_b[ks] = *(const bf16x8*)((const u16*)A.ws.b + sb + ly.w_off + wo);
-      }
-    }
-  };
-  if (has_job && mem < nchunk) load_w(mem);
-  f32x4 acc_a[2], acc_b[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    acc_a[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc_b[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  __syncthreads();
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  BNN_STAMP_DECL(A);
-  for (int c = 0; c < nchunk; ++c) {
-    stamp(c, 0);
-    const int slot = c % FW_SLOTS;
-    const u16* r_hi = raw + slot * pbytes;
-    const u16* r_lo = r_hi + (pbytes >> 1);
-    lds_barrier();   // B1: chunk c visible, chunk c-1 consumed
-    stamp(c, 2);
-    if constexpr (LRT) {
-      // squares of the bf16 hi plane (what the variance contraction sees)
-      for (int U = tid; U < DN_ROWS * 16; U += FW_THREADS) {
-        const uint4 h = *(const uint4*)&r_hi[U * 8];
-        const uint32_t hh[4] = {h.x, h.y, h.z, h.w};
-        uint32_t o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a = bf2f((u16)(hh[e] & 0xffff)), b = bf2f((u16)(hh[e] >> 16));
-          o[e] = (uint32_t)f2bf(a * a) | ((uint32_t)f2bf(b * b) << 16);
-        }
-        *(uint4*)&sqi[U * 8] = make_uint4(o[0], o[1], o[2], o[3]);
-      }
-      lds_barrier();  // B2
-    }
-    if (has_job && (c % F.members) == mem) {
-      const int nks = min(DN_CH, br.cin_p - c * DN_CH) >> 5;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < nks) {
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const int rr = mt * 16 + i16;
-            const int o = rr * DN_CH + (((ks * 4 + g4) ^ (rr & 15)) * 8);
-            const bf16x8 bh = *(const bf16x8*)&r_hi[o];
-            const bf16x8 bl = *(const bf16x8*)&r_lo[o];
-            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bh, acc_a[mt], 0, 0, 0);
-            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bl, acc_a[mt], 0, 0, 0);
-            acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[ks], bh, acc_a[mt], 0, 0, 0);
-            if constexpr (LRT) {
-              const bf16x8 b2 = *(const bf16x8*)&sqi[o];
-              acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], b2, acc_b[mt], 0, 0, 0);
-            } else if constexpr (EM == EM_FLIPOUT) {
-              // sign word of (row rr, k-step ks): byte g4 = this lane's 8 channels
-              const uint32_t word = sgn[slot * 128 + rr * 4 + ks];
-              const uint32_t byte = (word >> (8 * g4)) & 0xffu;
-              u32x4 fm;
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                fm[q] = (((byte >> (2 * q)) & 1u) << 15) | (((byte >> (2 * q + 1)) & 1u) << 31);
-              const u32x4 xb = __builtin_bit_cast(u32x4, bh) ^ fm;
-              acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], __builtin_bit_cast(bf16x8, xb), acc_b[mt], 0, 0, 0);
-            }
-          }
-        }
-      }
-      stamp(c, 3);
-      if (c + F.members < nchunk) load_w(c + F.members);   // lands while the other members work
-      stamp(c, 4);
-    }
-  }
-  // ---------------- reduction over the members of an n-tile ----------------
-  if (F.members > 1) {
-    if (has_job && mem > 0) {
-      float* r = red + (size_t)wave * (2 * 2 * 256);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        *(f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4] = acc_a[mt];
-        if constexpr (DUAL) *(f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4] = acc_b[mt];
-      }
-    }
-    lds_barrier();
-    if (has_job && mem == 0) {
-      for (int m = 1; m < F.members; ++m) {
-        const float* r = red + (size_t)(wave + m) * (2 * 2 * 256);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const f32x4 pa = *(const f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc_a[mt][q] += pa[q];
-          if constexpr (DUAL) {
-            const f32x4 pb = *(const f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc_b[mt][q] += pb[q];
-          }
-        }
-      }
-    }
-  }
-  // ---------------- epilogue (owner waves) ----------------
-  if (has_job && mem == 0) {
-    const int chb = nt * 16 + 4 * g4;
-    const int nv = br.cout - chb;
-    if (nv > 0) {
-      const TensorRef tout = A.t[br.out_t];
-      const float* ba = A.ws.bias_a + (long)A.ws.bias_stride_a * s + ly.bias_off + br.n_off + chb;
-      const float* bb = A.ws.bias_b + ly.bias_off + br.n_off + chb;
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const int row = mt * 16 + i16;
-        if (row >= W.nvalid) continue;
-        const int R = W.out_row0 + row;
-        f32x4 v = acc_a[mt];
-        f32x4 qv = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (LRT) {
-          f32x4 eps;
-          const int lch = br.n_off + chb;
-          if (A.nz.use_philox_lrt) {
-            const long Rg = global_row(A.cg, 1, R);
-            const uint64_t idx = (uint64_t)Rg * (uint64_t)(ly.cout_p16 >> 2) + (uint64_t)(lch >> 2);
-            eps = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)br.layer << 8), A.nz.step, A.nz.seed);
-          } else {
-            const float* e = A.nz.lrt_eps[br.layer] + (long)R * ly.cout + lch;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) eps[r] = (r < nv) ? e[r] : 0.f;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nv) {
-              const float loc = v[r] + ba[r];
-              float var = acc_b[mt][r] + bb[r];
-              if (var < 0.f) var = 1e-6f;
-              const float sd = sqrtf(var);
-              v[r] = loc + sd * eps[r];
-              qv[r] = sd > 0.f ? eps[r] / (2.f * sd) : 0.f;
-            }
-        } else if constexpr (EM == EM_FLIPOUT) {
-          const int bit0 = br.n_off + chb;
-          const uint32_t word = A.nz.sign_out[ly.sign_out_off * A.nz.examples + (long)(W.ex0 + row) * ly.sign_out_words + (bit0 >> 5)];
-          const uint32_t bits = word >> (bit0 & 31);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nv) {
-              const float pb = acc_b[mt][r];
-              v[r] = v[r] + ba[r] + (((bits >> r) & 1u) ? -pb : pb);
-            }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nv) v[r] += ba[r];
-        }
-        if (br.relu) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        const long oo = (long)R * tout.ctot + br.out_off + chb;
-        const bool vec = ((tout.ctot & 3) == 0) && ((br.out_off & 3) == 0);
-        tstore4(tout, oo, v, nv, vec);
-        if constexpr (LRT) {
-          const TensorRef tq = A.t[br.q_t];
-          tstore4(tq, (long)R * tq.ctot + br.out_off + chb, qv, nv, vec);
-        }
-      }
-    }
-  }
-}
+enum { DN_CH = 128, DN_ROWS = 32 };   // dense layers: channels per K chunk, example rows per window
 
 // ==========================================================================================
 // dense_dx_bf_kernel : dX of a dense layer (K = cout <= 64 is tiny, the output is wide).
@@ -2047,353 +712,6 @@ __global__ __launch_bounds__(1024) void dense_dx_bf_kernel(const GroupArgs A) {
         for (int r = 0; r < 4; ++r) v[r] += ((bits >> r) & 1u) ? -acc_b[mt][r] : acc_b[mt][r];
       }
       tstore4(tdx, (long)(W.in_row0 + row) * tdx.ctot + br.in_off + och, v, 4, true);
-    }
-  }
-}
-
-// ==========================================================================================
-// conv_dw_dma_kernel : dW of a conv group, role-specialised (8 compute waves + 4 LDS-DMA loaders).
-//   loaders : X hi plane + (dY, Y hi [, q]) sub-images of EVERY branch, two windows ahead;
-//   all     : dz = dY [Y>0] (LRT: dz2 = dz q), pooled X (max of bf16 is exact), LRT squares;
-//   compute : the dW tiles (branch, n-tile, tap, c-tile) of a wave stay in registers over all
-//             windows of the workgroup; operands through ds_read_b64_tr_b16 from the dense
-//             XOR-swizzled images; Flipout sign products are XORs on the fragments.
-// ==========================================================================================
-enum { DW_NC = 12, DW_THREADS = (DW_NC + FW_NL) * 64, DW_MAXT = 4, DW_KINDS = 2 };   // 16 waves: 128 VGPRs each
-
-// The branches of a group are dealt to DW_KINDS workgroup kinds: a workgroup stages X and the dz
-// sub-images of ITS branches only and keeps at most DW_MAXT dW tiles (x2 for LRT / Flipout) per
-// wave in registers.
-struct ConvDwSub {
-  int ntiles, ninst, has_pool, zelems;
-  int zbase[BNN_MAX_BRANCH];      // -1: branch not handled by this kind
-  DwTile tile[DW_NC * DW_MAXT];
-  DxInst inst[32];
-};
-struct ConvDw2Plan {
-  int nsplit, nslots, nkinds, pad_;
-  ConvDwSub sub[DW_KINDS];
-};
-
-template <int EM>
-__global__ __launch_bounds__(DW_THREADS) void conv_dw_dma_kernel(const GroupArgs A, const ConvDw2Plan DP) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool DUAL = (EM != EM_PLAIN);
-  constexpr bool LRT = (EM == EM_LRT);
-  constexpr int NPT = LRT ? 3 : 2;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const GroupDesc& G = A.g;
-  const int kind = blockIdx.x % DP.nkinds;
-  const ConvDwSub& D = DP.sub[kind];
-  const int bid = blockIdx.x / DP.nkinds;
-  const int s = bid / DP.nsplit, split = bid - s * DP.nsplit;
-  const int L = G.L, B = A.cg.B;
-  const int xw = G.in_cin_p, x8n = xw >> 3;
-  const int xbytes = IMG_ROWS * xw * 2, zbytes = D.zelems * 2;
-  const int slot_bytes = xbytes + NPT * zbytes;
-  // LDS: raw[nslots][X | dY | Y | q] | derived (only what the estimator needs): dz | pooled X |
-  //      dz2 | X^2 | pooled X^2 | sign words
-  const int NS = DP.nslots;
-  char* der = smem + NS * slot_bytes;
-  int doff = 0;
-  u16* dzi = (u16*)(der + doff); doff += zbytes;
-  u16* xp = (u16*)(der + doff); doff += D.has_pool ? xbytes : 0;
-  u16* dz2 = (u16*)(der + doff); doff += LRT ? zbytes : 0;
-  u16* xsq = (u16*)(der + doff); doff += LRT ? xbytes : 0;
-  u16* xpsq = (u16*)(der + doff); doff += (LRT && D.has_pool) ? xbytes : 0;
-  uint32_t* sgn = (uint32_t*)(der + doff);
-  {
-    const int total = (NS * slot_bytes + doff + 3 * 64 * 4 + DW_NC * DW_MAXT * 16) >> 2;
-    uint32_t* z = (uint32_t*)smem;
-    for (int k = tid; k < total; k += DW_THREADS) z[k] = 0u;
-  }
-  const TensorRef tin = A.t[G.in_t];
-  const bool is_loader = wave >= DW_NC;
-  const int lw = wave - DW_NC;
-  const int my_ninst = is_loader ? max(0, (D.ninst - lw + FW_NL - 1) / FW_NL) : 0;
-  const int nwin = (B - split + DP.nsplit - 1) / DP.nsplit;
-  auto win_of = [&](int k) { return split + k * DP.nsplit; };
-
-  const uint32_t* sg_src = nullptr;
-  long sg_stride = 0;
-  bool sg_ok = false;
-  if (EM == EM_FLIPOUT && is_loader && lw == 0 && lane < 8 * G.n_branch) {
-    const int b = lane >> 3, k = lane & 7;
-    const BranchDesc& br = G.br[b];
-    const LayerDesc& ly = A.layers[br.layer];
-    if (k < 4 && k < ly.sign_in_words) {
-      sg_src = A.nz.sign_in + ly.sign_in_off * A.nz.examples + k;
-      sg_stride = ly.sign_in_words;
-      sg_ok = true;
-    } else if (k >= 4 && k - 4 < ly.sign_out_words && k < 6) {
-      sg_src = A.nz.sign_out + ly.sign_out_off * A.nz.examples + (k - 4);
-      sg_stride = ly.sign_out_words;
-      sg_ok = true;
-    }
-  }
-  auto issue = [&](int k) {
-    const int wl = win_of(k);
-    const long w = (long)s * B + wl;
-    const long wx = G.in_bcast ? wl : w;
-    char* slot = smem + (k % NS) * slot_bytes;
-    int lane_o = lane;
-    asm volatile("" : "+v"(lane_o));
-    for (int i = 0; i < my_ninst; ++i) {
-      const DxInst I = D.inst[lw + i * FW_NL];
-      const int q = I.q0 + lane_o;
-      if (I.pt < 3) {
-        const BranchDesc& br = G.br[I.b];
-        const int cb8 = (br.cout + 7) >> 3;
-        const int row = q / cb8, p = q - row * cb8;
-        const int c8 = swz(p, row + HALO, cb8);
-        const TensorRef tt = I.pt == 0 ? A.t[br.out_t + T_GRAD] : (I.pt == 1 ? A.t[br.out_t] : A.t[br.q_t]);
-        const u16* src = (const u16*)tt.p + (w * L + row) * tt.ctot + br.out_off + c8 * 8;
-        char* dst = slot + xbytes + I.pt * zbytes + (D.zbase[I.b] + HALO * cb8 * 8) * 2 + I.q0 * 16;
-        if (q < L * cb8) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
-      } else {
-        const int row = q / x8n, p = q - row * x8n;
-        const int c8 = swz(p, row + HALO, x8n);
-        const u16* src = (const u16*)tin.p + (wx * L + row) * tin.ctot + c8 * 8;
-        char* dst = slot + HALO * xw * 2 + I.q0 * 16;
-        if (q < L * x8n) dma16(src, __builtin_amdgcn_readfirstlane(lds_addr(dst)));
-      }
-    }
-    if (EM == EM_FLIPOUT && lw == 0) {
-      if (sg_ok) dma4(sg_src + w * sg_stride, __builtin_amdgcn_readfirstlane(lds_addr(sgn + (k % NS) * 64)));
-    }
-  };
-  const int n_issue = my_ninst + ((EM == EM_FLIPOUT && lw == 0) ? 1 : 0);
-
-  // ---- per-thread derive plan: up to 2 dz units and 1 X unit (16 bytes each) ----
-  int m_o[2] = {-1, -1}, m_relu[2] = {0, 0};
-  {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      int U = tid + u * DW_THREADS;
-      for (int b = 0; b < G.n_branch; ++b) {
-        if (D.zbase[b] < 0) continue;
-        const int cb8 = (G.br[b].cout + 7) >> 3;
-        const int n = L * cb8;
-        if (U >= 0 && U < n) {
-          const int row = U / cb8, p = U - row * cb8;
-          m_o[u] = D.zbase[b] + (row + HALO) * cb8 * 8 + p * 8;
-          m_relu[u] = G.br[b].relu;
-          U = -1;
-        } else if (U >= n) {
-          U -= n;
-        }
-      }
-    }
-  }
-  const int x_units = L * x8n;
-
-  // ---- tiles of this compute wave: accumulators in registers, metadata in LDS (wave-uniform reads) ----
-  f32x4 acc_a[DW_MAXT], acc_b[DW_MAXT];
-  int* tmeta = (int*)(sgn + 3 * 64);   // [ntiles][4]: geo | zbase | sign_out word/bit | sign_in word/bit
-#pragma unroll
-  for (int m = 0; m < DW_MAXT; ++m) {
-    acc_a[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc_b[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  __syncthreads();   // zero fill done before the table is written
-  for (int t = tid; t < D.ntiles; t += DW_THREADS) {
-    const DwTile T = D.tile[t];
-    const BranchDesc& br = G.br[T.b];
-    const LayerDesc& ly = A.layers[br.layer];
-    const int cb8 = (br.cout + 7) >> 3;
-    const int nbit = br.n_off + T.nt * 16, cbit = T.ct * 16;
-    tmeta[t * 4 + 0] = cb8 | ((T.nt * 16) << 8) | ((br.in_off + T.ct * 16) << 16) | ((T.tap - ly.pad + 8) << 24) | (br.pool << 30);
-    tmeta[t * 4 + 1] = D.zbase[T.b];
-    tmeta[t * 4 + 2] = (T.b * 8 + 4 + (nbit >> 5)) | ((nbit & 31) << 8);
-    tmeta[t * 4 + 3] = (T.b * 8 + (cbit >> 5)) | ((cbit & 31) << 8);
-  }
-  float gb_a = 0.f, gb_b = 0.f;
-  // bias-gradient plan: thread tid < total couts sums one dz column
-  int bz_zb = -1, bz_cb8 = 1, bz_n = 0, bz_b = 0;
-  {
-    int U = tid;
-    for (int b = 0; b < G.n_branch; ++b) {
-      if (D.zbase[b] < 0) continue;
-      if (U >= 0 && U < G.br[b].cout) {
-        bz_zb = D.zbase[b];
-        bz_cb8 = (G.br[b].cout + 7) >> 3;
-        bz_n = U;
-        bz_b = b;
-        U = -1;
-      } else if (U >= G.br[b].cout) {
-        U -= G.br[b].cout;
-      }
-    }
-  }
-
-  __syncthreads();
-  const int ahead = NS - 1;
-  if (is_loader) {
-    for (int k = 0; k < ahead && k < nwin; ++k) issue(k);
-  }
-  const int gq = lane >> 4, qq = (lane >> 2) & 3, pq = lane & 3;
-  for (int k = 0; k < nwin; ++k) {
-    const int slotk = k % NS;
-    const u16* r_x = (const u16*)(smem + slotk * slot_bytes);
-    const u16* r_dy = (const u16*)(smem + slotk * slot_bytes + xbytes);
-    const u16* r_y = r_dy + (zbytes >> 1);
-    const u16* r_q = r_dy + zbytes;
-    if (is_loader) {
-      // windows k+1 .. k+ahead-1 may stay in flight
-      const int fly = min(ahead - 1, nwin - 1 - k);
-      if (fly >= 1) BNN_WAIT_VMCNT(n_issue);
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    lds_barrier();   // B1
-    // ---- derive: dz (, dz2), pooled X, squares ----
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (m_o[u] >= 0) {
-        uint4 g = *(const uint4*)&r_dy[m_o[u]];
-        if (m_relu[u]) {
-          const uint4 y = *(const uint4*)&r_y[m_o[u]];
-          auto msk = [](uint32_t yy) {
-            const uint32_t lo = ((yy & 0x8000u) == 0 && (yy & 0x7fffu) != 0) ? 0xffffu : 0u;
-            const uint32_t hi = ((yy & 0x80000000u) == 0 && (yy & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
-            return lo | hi;
-          };
-          g.x &= msk(y.x); g.y &= msk(y.y); g.z &= msk(y.z); g.w &= msk(y.w);
-        }
-        *(uint4*)&dzi[m_o[u]] = g;
-        if constexpr (LRT) {
-          const uint4 q4 = *(const uint4*)&r_q[m_o[u]];
-          const uint32_t gg[4] = {g.x, g.y, g.z, g.w}, qv[4] = {q4.x, q4.y, q4.z, q4.w};
-          uint32_t out[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float a0 = bf2f((u16)(gg[e] & 0xffff)) * bf2f((u16)(qv[e] & 0xffff));
-            const float a1 = bf2f((u16)(gg[e] >> 16)) * bf2f((u16)(qv[e] >> 16));
-            out[e] = (uint32_t)f2bf(a0) | ((uint32_t)f2bf(a1) << 16);
-          }
-          *(uint4*)&dz2[m_o[u]] = make_uint4(out[0], out[1], out[2], out[3]);
-        }
-      }
-    }
-    if (D.has_pool || LRT) {
-      for (int U = tid; U < x_units; U += DW_THREADS) {
-        const int row = U / x8n, p = U - row * x8n;
-        const int ri = row + HALO;
-        const int c8 = swz(p, ri, x8n) ;   // involution: channel chunk stored at position p
-        const int o = ri * xw + p * 8;
-        const uint4 h0 = *(const uint4*)&r_x[o];
-        uint32_t hh[4] = {h0.x, h0.y, h0.z, h0.w};
-        uint32_t pm[4] = {hh[0], hh[1], hh[2], hh[3]};
-        if (D.has_pool) {
-          auto mx = [](uint32_t a, uint32_t b) {
-            const float a0 = bf2f((u16)(a & 0xffff)), b0 = bf2f((u16)(b & 0xffff));
-            const float a1 = bf2f((u16)(a >> 16)), b1 = bf2f((u16)(b >> 16));
-            return (uint32_t)f2bf(fmaxf(a0, b0)) | ((uint32_t)f2bf(fmaxf(a1, b1)) << 16);
-          };
-          if (row > 0) {
-            const uint4 a = *(const uint4*)&r_x[(ri - 1) * xw + swz(c8, ri - 1, x8n) * 8];
-            pm[0] = mx(pm[0], a.x); pm[1] = mx(pm[1], a.y); pm[2] = mx(pm[2], a.z); pm[3] = mx(pm[3], a.w);
-          }
-          if (row + 1 < L) {
-            const uint4 a = *(const uint4*)&r_x[(ri + 1) * xw + swz(c8, ri + 1, x8n) * 8];
-            pm[0] = mx(pm[0], a.x); pm[1] = mx(pm[1], a.y); pm[2] = mx(pm[2], a.z); pm[3] = mx(pm[3], a.w);
-          }
-          *(uint4*)&xp[o] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
-        }
-        if constexpr (LRT) {
-          auto sq = [](uint32_t a) {
-            const float a0 = bf2f((u16)(a & 0xffff)), a1 = bf2f((u16)(a >> 16));
-            return (uint32_t)f2bf(a0 * a0) | ((uint32_t)f2bf(a1 * a1) << 16);
-          };
-          *(uint4*)&xsq[o] = make_uint4(sq(hh[0]), sq(hh[1]), sq(hh[2]), sq(hh[3]));
-          if (D.has_pool) *(uint4*)&xpsq[o] = make_uint4(sq(pm[0]), sq(pm[1]), sq(pm[2]), sq(pm[3]));
-        }
-      }
-    }
-    lds_barrier();   // B2
-    if (is_loader) {
-      if (k + ahead < nwin) issue(k + ahead);
-    }
-    // ---------------- tiles ----------------
-    if (!is_loader) {
-      const uint32_t* sg = sgn + slotk * 64;
-#pragma unroll
-      for (int m = 0; m < DW_MAXT; ++m) {
-        const int tix = wave + DW_NC * m;
-        if (tix < D.ntiles) {
-          const int geo = __builtin_amdgcn_readfirstlane(tmeta[tix * 4 + 0]);
-          const int tzb = __builtin_amdgcn_readfirstlane(tmeta[tix * 4 + 1]);
-          const int tso = __builtin_amdgcn_readfirstlane(tmeta[tix * 4 + 2]);
-          const int tsi = __builtin_amdgcn_readfirstlane(tmeta[tix * 4 + 3]);
-          const int cb8 = geo & 0xff, n0 = (geo >> 8) & 0xff, c0 = (geo >> 16) & 0xff;
-          const int tshift = ((geo >> 24) & 0x3f) - 8, pooled = (geo >> 30) & 1;
-          // lane 16g+4q+p: row (8g+q [+4]), columns 4p..4p+3 of the 16-column block
-          const int ra = 8 * gq + qq + HALO, rb = ra + tshift;
-          const int na = n0 + 4 * pq, cbx = c0 + 4 * pq;
-          const int zrow = cb8 * 8;
-          const u16* zi = dzi + tzb;
-          const u16* xi = pooled ? xp : r_x;
-          const u16* a0 = zi + ra * zrow + swz(na >> 3, ra, cb8) * 8 + (na & 7);
-          const u16* a1 = zi + (ra + 4) * zrow + swz(na >> 3, ra + 4, cb8) * 8 + (na & 7);
-          const u16* b0 = xi + rb * xw + swz(cbx >> 3, rb, x8n) * 8 + (cbx & 7);
-          const u16* b1 = xi + (rb + 4) * xw + swz(cbx >> 3, rb + 4, x8n) * 8 + (cbx & 7);
-          const bf16x8 fa = tr_frag(a0, a1);
-          const bf16x8 fb = tr_frag(b0, b1);
-          acc_a[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc_a[m], 0, 0, 0);
-          if constexpr (LRT) {
-            const u16* z2 = dz2 + tzb;
-            const u16* xs = pooled ? xpsq : xsq;
-            const long da = a0 - zi, da1 = a1 - zi, db = b0 - xi, db1 = b1 - xi;
-            acc_b[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(z2 + da, z2 + da1), tr_frag(xs + db, xs + db1),
-                                                               acc_b[m], 0, 0, 0);
-          } else if constexpr (EM == EM_FLIPOUT) {
-            const bool no = (sg[tso & 0xff] >> ((tso >> 8) + (lane & 15))) & 1u;
-            const bool ni = (sg[tsi & 0xff] >> ((tsi >> 8) + (lane & 15))) & 1u;
-            acc_b[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xor_sign(fa, no), xor_sign(fb, ni), acc_b[m], 0, 0, 0);
-          }
-        }
-      }
-      if (bz_zb >= 0) {
-        float sa = 0.f, sb = 0.f;
-        const int zrow = bz_cb8 * 8;
-        for (int r = 0; r < L; ++r) {
-          const int ri = r + HALO;
-          const int o = bz_zb + ri * zrow + swz(bz_n >> 3, ri, bz_cb8) * 8 + (bz_n & 7);
-          sa += bf2f(dzi[o]);
-          if constexpr (LRT) sb += bf2f(dz2[o]);
-        }
-        gb_a += sa;
-        gb_b += sb;
-      }
-    }
-  }
-  // ---- write out ----
-  if (!is_loader) {
-    const int i4 = 4 * (lane >> 4), jc = lane & 15;
-#pragma unroll
-    for (int m = 0; m < DW_MAXT; ++m) {
-      if (wave + DW_NC * m >= D.ntiles) continue;
-      const DwTile T = D.tile[wave + DW_NC * m];
-      const BranchDesc& br = G.br[T.b];
-      const LayerDesc& ly = A.layers[br.layer];
-      const int c = T.ct * 16 + jc;
-      if (c >= br.cin_p) continue;
-      float* gwa = A.gw_a + A.gw_stride * s + ly.w_off;
-      float* gwb = A.gw_b + A.gw_stride * s + ly.w_off;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = T.nt * 16 + i4 + r;
-        if (n >= br.cout) continue;
-        const long o = (long)(br.n_off + n) * ly.KP + (long)T.tap * ly.cin_img + c;
-        atomicAdd(gwa + o, acc_a[m][r]);
-        if constexpr (DUAL) atomicAdd(gwb + o, acc_b[m][r]);
-      }
-    }
-    if (bz_zb >= 0) {
-      const BranchDesc& br = G.br[bz_b];
-      const LayerDesc& ly = A.layers[br.layer];
-      atomicAdd(A.gb_a + (long)A.gb_stride * s + ly.bias_off + br.n_off + bz_n, gb_a);
-      if constexpr (LRT) atomicAdd(A.gb_b + (long)A.gb_stride * s + ly.bias_off + br.n_off + bz_n, gb_b);
     }
   }
 }

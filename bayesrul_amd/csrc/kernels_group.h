@@ -22,6 +22,7 @@ struct GroupArgs {
   unsigned char* amax;     // conv groups with a pooled branch: arg-max code (0 row-1, 1 row, 2 row+1) of
                            // MaxPool1d(3,1,1) per element of the input tensor, [windows * L][in_cin_p]; written by the
                            // forward, read by the fused dX
+  int dbg_block;           // diagnostics: workgroup whose waves record stamps
   unsigned long long* dbg;  // diagnostics only: phase time stamps of workgroup 0 ([wave][48 windows][8 phases]); null = off
 };
 

@@ -527,69 +527,6 @@ __global__ void pool_bwd_kernel(const TensorRef X, const TensorRef dP, const Ten
   tput(dX, idx, tget(dX, idx) + acc);
 }
 
-// bf16-plane version: one thread = 8 channels (16-byte loads) of one row; X = hi + lo planes,
-// dP / dX single bf16 planes.  C is a multiple of 8.
-__global__ void pool_bwd_bf_kernel(const u16* xh, const u16* xl, const u16* dP, u16* dX, long nwin, int L, int C) {
-  const int c8n = C >> 3;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= nwin * L * c8n) return;
-  const int c8 = (int)(idx % c8n);
-  const long rw = idx / c8n;
-  const int r = (int)(rw % L);
-  const long w = rw / L;
-  const long base = (w * L) * C + c8 * 8;
-  // values of rows r-2 .. r+2 (missing rows: -inf so they never win)
-  float xv[5][8];
-#pragma unroll
-  for (int d = 0; d < 5; ++d) {
-    const int rr = r + d - 2;
-    if (rr >= 0 && rr < L) {
-      const uint4 h = *(const uint4*)(xh + base + (long)rr * C);
-      const uint4 l = *(const uint4*)(xl + base + (long)rr * C);
-      const uint32_t hh[4] = {h.x, h.y, h.z, h.w}, ll[4] = {l.x, l.y, l.z, l.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        xv[d][2 * k] = bf2f((u16)(hh[k] & 0xffff)) + bf2f((u16)(ll[k] & 0xffff));
-        xv[d][2 * k + 1] = bf2f((u16)(hh[k] >> 16)) + bf2f((u16)(ll[k] >> 16));
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) xv[d][k] = -INFINITY;
-    }
-  }
-  float acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-#pragma unroll
-  for (int dp = 0; dp < 3; ++dp) {   // pooled position rp = r - 1 + dp, its window = rows rp-1..rp+1 = d index dp..dp+2
-    const int rp = r - 1 + dp;
-    if (rp < 0 || rp >= L) continue;
-    const uint4 g = *(const uint4*)(dP + base + (long)rp * C);
-    const uint32_t gg[4] = {g.x, g.y, g.z, g.w};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float a = xv[dp][k], b = xv[dp + 1][k], c = xv[dp + 2][k];
-      // first maximum wins (torch): argmax index among (a, b, c); row r sits at position 2 - dp
-      int am = 0;
-      float best = a;
-      if (b > best) { best = b; am = 1; }
-      if (c > best) { best = c; am = 2; }
-      if (a == -INFINITY && am == 0) am = (b >= c || c == -INFINITY) ? 1 : 2;  // missing first row
-      const float gv = bf2f((u16)((k & 1) ? (gg[k >> 1] >> 16) : (gg[k >> 1] & 0xffff)));
-      if (am == 2 - dp) acc[k] += gv;
-    }
-  }
-  const uint4 o = *(const uint4*)(dX + base + (long)r * C);
-  const uint32_t oo[4] = {o.x, o.y, o.z, o.w};
-  uint32_t out[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float v0 = bf2f((u16)(oo[k] & 0xffff)) + acc[2 * k];
-    const float v1 = bf2f((u16)(oo[k] >> 16)) + acc[2 * k + 1];
-    out[k] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-  }
-  *(uint4*)(dX + base + (long)r * C) = make_uint4(out[0], out[1], out[2], out[3]);
-}
 
 // ------------------------------------------------------------------------------------------
 // predictive aggregation over particles (A16), two-pass variance

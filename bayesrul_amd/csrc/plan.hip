@@ -114,6 +114,7 @@ struct BnnPlan {
   Prof prof;
   unsigned long long* dbg_buf = nullptr;   // diagnostics only (bnn_debug_stamps): device stamp buffer
   int dbg_tag = -1;                        // kind * 16 + group of the launch that records stamps
+  int dbg_block = 0;                       // workgroup that records
   int n_layers = 0, n_sites = 0, n_groups = 0;
   long P = 0;
   std::vector<std::string> site_names, layer_names;
@@ -753,6 +754,7 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
   }
   A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), nullptr, 128, p->d.prec == BNN_PREC_BF16X3 ? TF_BF16 : TF_F32};
   A->amax = nullptr;
+  A->dbg_block = p->dbg_block;
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION)
     for (int b = 0; b < A->g.n_branch; ++b)
       if (A->g.br[b].pool && A->g.br[b].dx_t >= 0) A->amax = (unsigned char*)w + p->o_amax;
@@ -845,86 +847,7 @@ static int launch_dw(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int 
   return 0;
 }
 
-// ---- round-1 optimised bf16 conv-group kernels (kernels_conv_bf.h) ----
-static int build_conv_fwd_plan(const GroupArgs& A, const LayerDesc* layers, ConvFwdPlan* F, int* ks_needed) {
-  *F = ConvFwdPlan{};
-  for (int w = 0; w < CV_WAVES; ++w)
-    for (int j = 0; j < 2; ++j) F->job[w][j].b = -1;
-  struct Tile { int b, nt, ks; };
-  std::vector<Tile> tiles;
-  int total_ks = 0;
-  for (int b = 0; b < A.g.n_branch; ++b) {
-    const BranchDesc& br = A.g.br[b];
-    const LayerDesc& ly = layers[br.layer];
-    if (br.pool) F->has_pool = 1;
-    const int ks = (ly.taps * (br.cin_p / 8) + 3) / 4;
-    for (int n = 0; n < br.ntiles; ++n) {
-      tiles.push_back({b, n, ks});
-      total_ks += ks;
-    }
-  }
-  int maxks = 0;
-  if ((int)tiles.size() <= 4) {
-    // few n-tiles: split K across waves, members of a group are consecutive waves
-    std::vector<int> nm(tiles.size(), 1);
-    int used = (int)tiles.size();
-    while (used < CV_WAVES) {  // give the next wave to the tile with the most k-steps per member
-      int best = 0;
-      double bv = -1;
-      for (size_t t = 0; t < tiles.size(); ++t) {
-        const double v = (double)tiles[t].ks / nm[t];
-        if (v > bv && nm[t] < tiles[t].ks) { bv = v; best = (int)t; }
-      }
-      if (bv < 0) break;
-      nm[best]++;
-      used++;
-    }
-    int w = 0;
-    for (size_t t = 0; t < tiles.size(); ++t) {
-      for (int m = 0; m < nm[t]; ++m, ++w) {
-        FwdJob& J = F->job[w][0];
-        J.b = (signed char)tiles[t].b;
-        J.nt = (signed char)tiles[t].nt;
-        J.ks0 = (signed char)(tiles[t].ks * m / nm[t]);
-        J.ks1 = (signed char)(tiles[t].ks * (m + 1) / nm[t]);
-        J.grp = nm[t] > 1 ? (signed char)t : -1;
-        J.owner = m == 0;
-        J.member = (signed char)m;
-        J.nmember = (signed char)nm[t];
-        maxks = std::max(maxks, J.ks1 - J.ks0);
-        if (nm[t] > 1) F->n_red_groups = (int)tiles.size();
-      }
-    }
-  } else {
-    // longest-processing-time onto the 4 SIMDs (waves w and w+4 share a SIMD), <= 2 jobs per wave
-    std::sort(tiles.begin(), tiles.end(), [](const Tile& a, const Tile& b) { return a.ks > b.ks; });
-    int simd_load[4] = {0, 0, 0, 0}, njobs[CV_WAVES] = {0};
-    for (const Tile& t : tiles) {
-      int bw = -1;
-      for (int w = 0; w < CV_WAVES; ++w) {
-        if (njobs[w] >= 2) continue;
-        if (bw < 0) { bw = w; continue; }
-        const int a = simd_load[w & 3] * 4 + njobs[w], b = simd_load[bw & 3] * 4 + njobs[bw];
-        if (a < b) bw = w;
-      }
-      if (bw < 0) return fail(BNN_E_INVALID, "conv fwd plan: more than 16 n-tiles");
-      FwdJob& J = F->job[bw][njobs[bw]++];
-      J.b = (signed char)t.b;
-      J.nt = (signed char)t.nt;
-      J.ks0 = 0;
-      J.ks1 = (signed char)t.ks;
-      J.grp = -1;
-      J.owner = 1;
-      J.member = 0;
-      J.nmember = 1;
-      simd_load[bw & 3] += t.ks;
-      maxks = std::max(maxks, t.ks);
-    }
-  }
-  *ks_needed = maxks;
-  return 0;
-}
-
+// ---- bf16-plane kernels of the conv groups and the dense layers (kernels_conv_bf.h, kernels_conv_dx.h, kernels_dense_fwd.h) ----
 // jobs of the role-specialised forward (one per compute wave): tiles whose K exceeds FW_KS k-steps
 // are split, then the longest jobs keep being split until all `nc` compute waves have work.
 // `mask` selects the branches of this workgroup kind.
@@ -1048,40 +971,6 @@ static int launch_conv_fwd_dma(const GroupArgs& A0, const LayerDesc* layers, int
   return launch_conv_fwd_dma_t<FW_NC, FW_NL>(A, F, em, lds, grid, st);
 }
 
-static int launch_conv_fwd_bf(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
-  GroupArgs A = A0;
-  ConvFwdPlan F;
-  int ks = 0;
-  BNN_TRY(build_conv_fwd_plan(A, layers, &F, &ks));
-  int maxj = 0;
-  for (int w = 0; w < CV_WAVES; ++w) maxj = std::max(maxj, (F.job[w][0].b >= 0) + (F.job[w][1].b >= 0));
-  const bool one = maxj <= 1;
-  if ((one && ks > 5) || (!one && ks > 4))
-    return fail(BNN_E_INVALID, "conv fwd plan needs %d k-steps x %d jobs per wave (compiled: 5x1, 4x2)", ks, maxj);
-  if (A.g.L * (A.g.in_cin_p / 8) * 2 > 2 * CV_THREADS) return fail(BNN_E_INVALID, "conv fwd staging exceeds 2 units per thread");
-  F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
-  const int pbytes = (IMG_ROWS * img_row_stride(A.g.in_cin_p, true) * 2 + 15) & ~15;
-  const int lds = 6 * pbytes + (F.n_red_groups > 0 ? CV_WAVES * 4 * 256 * 4 : 0);
-  const unsigned grid = (unsigned)(A.cg.S * F.nsplit);
-  ProfScope ps_(pf, PK_FWD, gi, st);
-#define LAUNCH_FWD(EMV)                                                                      \
-  do {                                                                                       \
-    if (one) {                                                                               \
-      BNN_TRY(set_lds(conv_fwd_bf_kernel<EMV, 5, 1>, lds));                                  \
-      conv_fwd_bf_kernel<EMV, 5, 1><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, F);        \
-    } else {                                                                                 \
-      BNN_TRY(set_lds(conv_fwd_bf_kernel<EMV, 4, 2>, lds));                                  \
-      conv_fwd_bf_kernel<EMV, 4, 2><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, F);        \
-    }                                                                                        \
-  } while (0)
-  if (em == EM_PLAIN) LAUNCH_FWD(EM_PLAIN);
-  else if (em == EM_LRT) LAUNCH_FWD(EM_LRT);
-  else LAUNCH_FWD(EM_FLIPOUT);
-#undef LAUNCH_FWD
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 static void build_conv_dw_plan(const GroupArgs& A, const LayerDesc* layers, ConvDwPlan* D) {
   *D = ConvDwPlan{};
   int zo = 0, nt = 0;
@@ -1102,43 +991,6 @@ static void build_conv_dw_plan(const GroupArgs& A, const LayerDesc* layers, Conv
   }
   D->ntiles = nt;
   D->zw = zo;
-}
-
-template <int EM>
-static int launch_conv_dw_bf_em(const GroupArgs& A, const ConvDwPlan& D, int lds, unsigned grid, hipStream_t st) {
-  const int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
-  if (tpw <= 4) {
-    BNN_TRY(set_lds(conv_dw_bf_kernel<EM, 4, 2, 3>, lds));
-    conv_dw_bf_kernel<EM, 4, 2, 3><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
-  } else if (tpw <= 6) {
-    BNN_TRY(set_lds(conv_dw_bf_kernel<EM, 6, 2, 3>, lds));
-    conv_dw_bf_kernel<EM, 6, 2, 3><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
-  } else {
-    BNN_TRY(set_lds(conv_dw_bf_kernel<EM, 11, 2, 3>, lds));
-    conv_dw_bf_kernel<EM, 11, 2, 3><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-static int launch_conv_dw_bf(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
-  GroupArgs A = A0;
-  ConvDwPlan D;
-  build_conv_dw_plan(A, layers, &D);
-  if (D.ntiles > 96 || (D.ntiles + CV_WAVES - 1) / CV_WAVES > 11) return fail(BNN_E_INVALID, "conv dW plan too large");
-  D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
-  const int xw16 = rup(A.g.in_cin_p, 16);
-  const int xbytes = (IMG_ROWS * img_row_stride(xw16, true) * 2 + 15) & ~15;
-  const int zbytes = (IMG_ROWS * img_row_stride(D.zw, true) * 2 + 15) & ~15;
-  const int lds = 4 * xbytes + 2 * zbytes;
-  const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
-  // staging-unit capacity of the instantiations: XU = 2, ZU = 3 float4 per thread
-  if (A.g.L * (A.g.in_cin_p / 4) > 2 * CV_THREADS || A.g.L * (D.zw / 4) > 3 * CV_THREADS)
-    return fail(BNN_E_INVALID, "conv dW staging plan exceeds the compiled unit counts");
-  ProfScope ps_(pf, PK_DW, gi, st);
-  if (em == EM_PLAIN) return launch_conv_dw_bf_em<EM_PLAIN>(A, D, lds, grid, st);
-  if (em == EM_LRT) return launch_conv_dw_bf_em<EM_LRT>(A, D, lds, grid, st);
-  return launch_conv_dw_bf_em<EM_FLIPOUT>(A, D, lds, grid, st);
 }
 
 template <int EM, int NWI>
@@ -1192,95 +1044,6 @@ static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int e
 #undef DISPATCH_NWI
 }
 
-static int launch_conv_dw_dma(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
-  GroupArgs A = A0;
-  static thread_local ConvDw2Plan D;   // large; copied into the kernel arguments at launch
-  D = ConvDw2Plan{};
-  const int L = A.g.L, npt = em == EM_LRT ? 3 : 2;
-  const int x8n = A.g.in_cin_p / 8;
-  if (x8n != 4 && x8n != 16) return fail(BNN_E_INVALID, "conv dW: input of %d channels", A.g.in_cin_p);
-  // deal the branches to the kinds: heaviest first onto the lighter kind
-  int ntile_b[BNN_MAX_BRANCH], order[BNN_MAX_BRANCH], load[DW_KINDS] = {0, 0}, kind_of[BNN_MAX_BRANCH];
-  for (int b = 0; b < A.g.n_branch; ++b) {
-    const BranchDesc& br = A.g.br[b];
-    ntile_b[b] = br.ntiles * layers[br.layer].taps * ((br.cin_p + 15) / 16);
-    order[b] = b;
-  }
-  std::sort(order, order + A.g.n_branch, [&](int x, int y) { return ntile_b[x] > ntile_b[y]; });
-  D.nkinds = A.g.n_branch > 1 ? DW_KINDS : 1;
-  for (int i = 0; i < A.g.n_branch; ++i) {
-    const int b = order[i];
-    const int k = (D.nkinds > 1 && load[1] < load[0]) ? 1 : 0;
-    kind_of[b] = k;
-    load[k] += ntile_b[b];
-  }
-  int lds_max = 0, slot_max = 0, der_max = 0;
-  for (int k = 0; k < D.nkinds; ++k) {
-    ConvDwSub& S = D.sub[k];
-    int zel = 0, nt = 0, ni = 0, units = 0;
-    for (int b = 0; b < A.g.n_branch; ++b) {
-      const BranchDesc& br = A.g.br[b];
-      const LayerDesc& ly = layers[br.layer];
-      S.zbase[b] = -1;
-      if (kind_of[b] != k) continue;
-      const int cb8 = (br.cout + 7) / 8;
-      if (16 % cb8) return fail(BNN_E_INVALID, "conv dW: branch cout %d unsupported", br.cout);
-      S.zbase[b] = zel;
-      zel += IMG_ROWS * cb8 * 8;
-      units += L * cb8;
-      if (br.pool) S.has_pool = 1;
-      const int ctiles = (br.cin_p + 15) / 16;
-      for (int n = 0; n < br.ntiles; ++n)
-        for (int t = 0; t < ly.taps; ++t)
-          for (int c = 0; c < ctiles; ++c) {
-            if (nt >= DW_NC * DW_MAXT) return fail(BNN_E_INVALID, "conv dW: more than %d tiles per workgroup kind", DW_NC * DW_MAXT);
-            S.tile[nt++] = DwTile{(signed char)b, (signed char)n, (signed char)t, (signed char)c};
-          }
-    }
-    S.ntiles = nt;
-    S.zelems = zel;
-    for (int q0 = 0; q0 < L * x8n; q0 += 64) S.inst[ni++] = DxInst{3, 0, (short)q0};
-    for (int pt = 0; pt < npt; ++pt)
-      for (int b = 0; b < A.g.n_branch; ++b) {
-        if (S.zbase[b] < 0 || (pt == 1 && !A.g.br[b].relu)) continue;
-        const int nchunk = L * ((A.g.br[b].cout + 7) / 8);
-        for (int q0 = 0; q0 < nchunk; q0 += 64) {
-          if (ni >= 32) return fail(BNN_E_INVALID, "conv dW: DMA table overflow");
-          S.inst[ni++] = DxInst{(signed char)pt, (signed char)b, (short)q0};
-        }
-      }
-    S.ninst = ni;
-    if ((ni + FW_NL - 1) / FW_NL + 1 > 12) return fail(BNN_E_INVALID, "conv dW: too many DMA instructions per loader");
-    if (units > 2 * DW_THREADS) return fail(BNN_E_INVALID, "conv dW: derive plan too large");
-    const int xbytes = IMG_ROWS * A.g.in_cin_p * 2, zbytes = zel * 2;
-    const int slot_bytes = xbytes + npt * zbytes;
-    const int der = zbytes + (S.has_pool ? xbytes : 0) + (em == EM_LRT ? zbytes + xbytes + (S.has_pool ? xbytes : 0) : 0) +
-                    3 * 64 * 4 + DW_NC * DW_MAXT * 16;
-    slot_max = std::max(slot_max, slot_bytes);
-    der_max = std::max(der_max, der);
-  }
-  D.nslots = (3 * slot_max + der_max > 160 * 1024) ? 2 : 3;
-  lds_max = D.nslots * slot_max + der_max;
-  if (lds_max > 160 * 1024) return fail(BNN_E_INVALID, "conv dW: %d bytes of LDS", lds_max);
-  D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
-  const unsigned grid = (unsigned)(D.nkinds * A.cg.S * D.nsplit);
-  const int lds = lds_max;
-  ProfScope ps_(pf, PK_DW, gi, st);
-  ps_.name("conv_dw_dma_kernel<%d>", em);
-  if (em == EM_PLAIN) {
-    BNN_TRY(set_lds(conv_dw_dma_kernel<EM_PLAIN>, lds));
-    conv_dw_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(DW_THREADS), lds, st>>>(A, D);
-  } else if (em == EM_LRT) {
-    BNN_TRY(set_lds(conv_dw_dma_kernel<EM_LRT>, lds));
-    conv_dw_dma_kernel<EM_LRT><<<dim3(grid), dim3(DW_THREADS), lds, st>>>(A, D);
-  } else {
-    BNN_TRY(set_lds(conv_dw_dma_kernel<EM_FLIPOUT>, lds));
-    conv_dw_dma_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DW_THREADS), lds, st>>>(A, D);
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 static int launch_dense_dw_bf(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   const BranchDesc& br = A.g.br[0];
@@ -1294,79 +1057,6 @@ static int launch_dense_dw_bf(const GroupArgs& A0, int em, hipStream_t st, Prof*
   if (em == EM_PLAIN) dense_dw_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
   else if (em == EM_LRT) dense_dw_bf_kernel<EM_LRT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
   else dense_dw_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-static int launch_conv_dx_dma(const GroupArgs& A0, const LayerDesc* layers, int em, int pool_sel, hipStream_t st, Prof* pf,
-                              int gi) {
-  GroupArgs A = A0;
-  ConvDxPlan D{};
-  D.pool_sel = pool_sel;
-  D.ntile = A.g.in_cin_p / 16;
-  const int L = A.g.L;
-  const int npt = em == EM_LRT ? 3 : 2;
-  int zel = 0, nks = 0, slot = 0, units = 0;
-  for (int b = 0; b < A.g.n_branch; ++b) {
-    const BranchDesc& br = A.g.br[b];
-    D.zbase[b] = -1;
-    if (br.pool != pool_sel || br.dx_t < 0) continue;
-    const LayerDesc& ly = layers[br.layer];
-    if (br.cout % 8 || (16 % (br.cout / 8)) != 0) return fail(BNN_E_INVALID, "conv dX: branch cout %d unsupported", br.cout);
-    if (slot >= DX_MAXB) return fail(BNN_E_INVALID, "conv dX: more than %d branches", DX_MAXB);
-    D.zbase[b] = zel;
-    zel += IMG_ROWS * br.cout;
-    units += L * (br.cout / 8);
-    const int ks = (ly.taps * (ly.cout_p8 / 8) + 3) / 4;
-    for (int i = 0; i < ks; ++i) {
-      if (nks >= DX_KS) return fail(BNN_E_INVALID, "conv dX: more than %d k-steps", DX_KS);
-      D.ks_b[nks] = (signed char)b;
-      D.ks_i[nks] = (signed char)i;
-      D.ks_slot[nks] = (signed char)slot;
-      ++nks;
-    }
-    ++slot;
-  }
-  if (slot == 0) return 0;
-  if (units > DX_THREADS) return fail(BNN_E_INVALID, "conv dX: mask pass needs %d units", units);
-  if (D.ntile > DX_NC) return fail(BNN_E_INVALID, "conv dX: %d tiles exceed the compute waves", D.ntile);
-  D.nks = nks;
-  D.zelems = zel;
-  int ni = 0;
-  for (int pt = 0; pt < npt; ++pt)
-    for (int b = 0; b < A.g.n_branch; ++b) {
-      if (D.zbase[b] < 0) continue;
-      if (pt == 1 && !A.g.br[b].relu) continue;
-      const int nchunk = L * (A.g.br[b].cout / 8);
-      for (int q0 = 0; q0 < nchunk; q0 += 64) {
-        if (ni >= DX_MAXI) return fail(BNN_E_INVALID, "conv dX: DMA table overflow");
-        D.inst[ni++] = DxInst{(signed char)pt, (signed char)b, (short)q0};
-      }
-    }
-  if (em == EM_LRT)
-    for (int q0 = 0; q0 < L * (A.g.in_cin_p / 8); q0 += 64) {
-      if (ni >= DX_MAXI) return fail(BNN_E_INVALID, "conv dX: DMA table overflow");
-      D.inst[ni++] = DxInst{3, 0, (short)q0};
-    }
-  D.ninst = ni;
-  if ((ni + FW_NL - 1) / FW_NL + 1 > 12) return fail(BNN_E_INVALID, "conv dX: too many DMA instructions per loader");
-  D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
-  const int zbytes = zel * 2, xbytes = em == EM_LRT ? IMG_ROWS * A.g.in_cin_p * 2 : 0;
-  const int lds = FW_SLOTS * (npt * zbytes + xbytes) + 2 * zbytes + FW_SLOTS * 64 * 4;
-  if (lds > 160 * 1024) return fail(BNN_E_INVALID, "conv dX: %d bytes of LDS", lds);
-  const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
-  ProfScope ps_(pf, PK_DX, gi, st);
-  ps_.name("conv_dx_dma_kernel<%d>", em);
-  if (em == EM_PLAIN) {
-    BNN_TRY(set_lds(conv_dx_dma_kernel<EM_PLAIN>, lds));
-    conv_dx_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(DX_THREADS), lds, st>>>(A, D);
-  } else if (em == EM_LRT) {
-    BNN_TRY(set_lds(conv_dx_dma_kernel<EM_LRT>, lds));
-    conv_dx_dma_kernel<EM_LRT><<<dim3(grid), dim3(DX_THREADS), lds, st>>>(A, D);
-  } else {
-    BNN_TRY(set_lds(conv_dx_dma_kernel<EM_FLIPOUT>, lds));
-    conv_dx_dma_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DX_THREADS), lds, st>>>(A, D);
-  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1496,32 +1186,6 @@ static bool dense_dma_ok(const GroupArgs& A) {
   return (br.cin_p % 32) == 0 && br.ntiles <= 4 && br.cin_real == br.cin_p && br.in_off == 0 && (A.t[A.g.in_t].ctot % 8) == 0;
 }
 
-static int launch_dense_fwd_dma(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
-  GroupArgs A = A0;
-  DenseFwdPlan F{};
-  const BranchDesc& br = A.g.br[0];
-  F.ntile = br.ntiles;
-  F.nchunk = (br.cin_p + DN_CH - 1) / DN_CH;
-  F.members = std::max(1, std::min(FW_NC / F.ntile, F.nchunk));
-  const int pbytes = DN_ROWS * DN_CH * 2;
-  const int lds = (FW_SLOTS * 2 + 1) * pbytes + FW_SLOTS * 128 * 4 + FW_NC * 4 * 256 * 4;
-  const unsigned grid = (unsigned)A.cg.nwin;
-  ProfScope ps_(pf, PK_FWD, gi, st);
-  ps_.name("dense_fwd_dma_kernel<%d>", em);
-  if (em == EM_PLAIN) {
-    BNN_TRY(set_lds(dense_fwd_dma_kernel<EM_PLAIN>, lds));
-    dense_fwd_dma_kernel<EM_PLAIN><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
-  } else if (em == EM_LRT) {
-    BNN_TRY(set_lds(dense_fwd_dma_kernel<EM_LRT>, lds));
-    dense_fwd_dma_kernel<EM_LRT><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
-  } else {
-    BNN_TRY(set_lds(dense_fwd_dma_kernel<EM_FLIPOUT>, lds));
-    dense_fwd_dma_kernel<EM_FLIPOUT><<<dim3(grid), dim3(FW_THREADS), lds, st>>>(A, F);
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 // one-branch dense forward, 6-wave workgroups without K split (kernels_dense_fwd.h)
 static int launch_dense_fwd2(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
@@ -1579,9 +1243,9 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
     if (!bf)
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
-      BNN_TRY((getenv("BNN_FWD_REGSTAGE") ? launch_conv_fwd_bf : launch_conv_fwd_dma)(A, p->layers, c->em, c->st, &p->prof, gi));
-    else if (dense_dma_ok(A) && !getenv("BNN_DENSE_GENERIC"))
-      BNN_TRY((getenv("BNN_DENSE_V1") ? launch_dense_fwd_dma : launch_dense_fwd2)(A, c->em, c->st, &p->prof, gi));
+      BNN_TRY(launch_conv_fwd_dma(A, p->layers, c->em, c->st, &p->prof, gi));
+    else if (dense_dma_ok(A))
+      BNN_TRY(launch_dense_fwd2(A, c->em, c->st, &p->prof, gi));
     else
       BNN_TRY(launch_fwd<PrecBF>(A, c->em, c->st, &p->prof, gi));
   }
@@ -1624,7 +1288,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
     else if (!A.g.is_dense)
-      BNN_TRY((getenv("BNN_DW_DMA") ? launch_conv_dw_dma : (getenv("BNN_DW_V1") ? launch_conv_dw_bf : launch_conv_dw_mw))(A, p->layers, c->em, c->st, &p->prof, gi));
+      BNN_TRY(launch_conv_dw_mw(A, p->layers, c->em, c->st, &p->prof, gi));
     else if (A.g.n_branch == 1 && !A.g.in_bcast && A.g.br[0].cout <= 64 && (A.g.br[0].cout % 8) == 0 &&
              (A.g.br[0].cin_p % 16) == 0 && A.g.br[0].cin_real == A.g.br[0].cin_p && A.t[A.g.in_t].fmt == TF_BF16 &&
              (A.t[A.g.in_t].ctot % 8) == 0 && (A.t[A.g.br[0].out_t].ctot % 8) == 0 && A.t[A.g.br[0].out_t].fmt == TF_BF16)
@@ -1637,7 +1301,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       (A.g.br[b].pool ? any_pool : any_direct) = true;
     }
     const bool conv_bf = p->d.prec == BNN_PREC_BF16X3 && !A.g.is_dense;
-    if (conv_bf && (any_direct || any_pool) && !getenv("BNN_DX_V1")) {
+    if (conv_bf && (any_direct || any_pool)) {
       // one launch: direct and pooled branches, arg-max scatter included
       A.dbg = dbg_for(p, PK_DX, gi);
       BNN_TRY(launch_conv_dx2(A, p->layers, c->em, c->st, &p->prof, gi));
@@ -1647,8 +1311,6 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     if (any_direct) {
       if (p->d.prec == BNN_PREC_F32)
         BNN_TRY(launch_dx<PrecF32>(A, c->em, 0, c->st, &p->prof, gi));
-      else if (conv_bf)
-        BNN_TRY(launch_conv_dx_dma(A, p->layers, c->em, 0, c->st, &p->prof, gi));
       else if (A.g.is_dense && A.g.n_branch == 1 && A.g.br[0].cout <= 64 && (A.g.br[0].cin_p % 16) == 0 &&
                A.g.br[0].cin_real == A.g.br[0].cin_p && (A.t[A.g.br[0].dx_t].ctot % 4) == 0)
         BNN_TRY(launch_dense_dx_bf(A, c->em, c->st, &p->prof, gi));
@@ -1659,8 +1321,6 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     if (any_pool) {
       if (p->d.prec == BNN_PREC_F32)
         BNN_TRY(launch_dx<PrecF32>(A, c->em, 1, c->st, &p->prof, gi));
-      else if (conv_bf)
-        BNN_TRY(launch_conv_dx_dma(A, p->layers, c->em, 1, c->st, &p->prof, gi));
       else
         BNN_TRY(launch_dx<PrecBF>(A, c->em, 1, c->st, &p->prof, gi));
       // scatter through the arg-max of MaxPool1d(3,1,1) into the direct gradient
@@ -1669,16 +1329,9 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       const int C = p->tens[tin].ctot, L = A.g.L;
       const long n = nwin * L * C;
       ProfScope ps_(&p->prof, PK_POOLBWD, gi, c->st);
-      ps_.name(p->d.prec == BNN_PREC_BF16X3 && (C % 8) == 0 ? "pool_bwd_bf_kernel" : "pool_bwd_kernel");
-      if (p->d.prec == BNN_PREC_BF16X3 && (C % 8) == 0) {
-        const long n8 = nwin * L * (C / 8);
-        pool_bwd_bf_kernel<<<dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, c->st>>>(
-            (const u16*)A.t[tin].p, (const u16*)A.t[tin].lo, (const u16*)A.t[T_POOLGRAD].p,
-            (u16*)A.t[tin + T_GRAD].p, nwin, L, C);
-      } else {
-        pool_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(
-            A.t[tin], A.t[T_POOLGRAD], A.t[tin + T_GRAD], nwin, L, C);
-      }
+      ps_.name("pool_bwd_kernel");
+      pool_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(
+          A.t[tin], A.t[T_POOLGRAD], A.t[tin + T_GRAD], nwin, L, C);
       HIP_TRY(hipGetLastError());
     }
   }
@@ -1991,6 +1644,11 @@ extern "C" int bnn_profile_read(BnnPlan* p, int32_t* tags, double* ms, int64_t* 
 
 // diagnostics only (not part of the ABI of include/bayesrul_amd.h): phase time stamps of workgroup 0 of
 // the launch tagged kind * 16 + group (kinds: fwd 0, dx 1, dw 2, pooled dx 7); tag < 0 switches it off.
+extern "C" int bnn_debug_stamps_block(BnnPlan* p, int block) {
+  if (!p) return fail(BNN_E_INVALID, "null plan");
+  p->dbg_block = block;
+  return 0;
+}
 extern "C" int bnn_debug_stamps(BnnPlan* p, int tag) {
   if (!p) return fail(BNN_E_INVALID, "null plan");
   if (tag >= 0 && !p->dbg_buf) HIP_TRY(hipMalloc((void**)&p->dbg_buf, DBG_STAMP_BYTES));

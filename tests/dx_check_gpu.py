@@ -1,40 +1,34 @@
-"""Diagnostic (not a test): per-site gradient error of the bf16x3 Inception step against the oracle,
-for the fused conv dX kernel (default) and the previous one (BNN_DX_V1=1), all estimators."""
-import os
+"""Diagnostic (not a test): per-site gradient error of the bf16x3 Inception step against the oracle and
+run-to-run reproducibility (two fresh engines, identical inputs and injected noise), all estimators."""
 import sys
 
 import torch
 
 sys.path.insert(0, ".")
-from oracle import restatement as R  # noqa: E402
+from oracle import restatement as R  # noqa: E402,F401
 from tests.noise_util import rel_l2, to_injected  # noqa: E402
 from tests.test_gpu_parity import N_DATA, _setup  # noqa: E402
 
 for mode in ("flipout", "lrt", "radial"):
     S, B = 2, 100
-    grads = {}
-    for v1 in (True, False):
-        if v1:
-            os.environ["BNN_DX_V1"] = "1"
-        else:
-            os.environ.pop("BNN_DX_V1", None)
+    runs = []
+    for rep in range(2):
         eng, cfg, st_, x, y, noise, (ps, qs, lr) = _setup("inception", mode, "bf16x3", S, B, q_boost=5.0)
-        if v1:
+        if rep == 0:
             st = st_
+            loss_o, aux = st.loss_and_grads(x, y, noise)
         inj = to_injected(eng, cfg, noise, B)
         res, preds = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, noise=inj, want_preds=True)
         torch.cuda.synchronize()
-        grads[v1] = eng.grad.cpu().clone()
-        if v1:
-            loss_o, aux = st.loss_and_grads(x, y, noise)
-        print(f"{mode} v1={v1} loss {float(res[0]):.8g} oracle {float(loss_o):.8g}")
-    print(f"== {mode}: per-site rel-L2 vs oracle   [mu old, mu new | rho old, rho new]   new-vs-old mu")
+        runs.append((float(res[0]), eng.grad.cpu().clone(), preds.cpu().clone()))
+    (l0, g0, p0), (l1, g1, p1) = runs
+    print(f"== {mode}: loss {l0:.9g} / {l1:.9g}  oracle {float(loss_o):.9g}  rel err {abs(l0 - float(loss_o)) / abs(float(loss_o)):.2e}")
+    print(f"   run-to-run: loss diff {abs(l0 - l1):.3e}  preds max diff {float((p0 - p1).abs().max()):.3e}  "
+          f"grad rel-L2 {rel_l2(g1, g0.double()):.3e}")
     worst = 0.0
     for s, off, num in eng.sites:
-        gm, gr = st.mu[s].grad, st.rho[s].grad
-        e = [rel_l2(grads[v][off:off + num], gm) for v in (True, False)]
-        r = [rel_l2(grads[v][eng.P + off:eng.P + off + num], gr) for v in (True, False)]
-        d = rel_l2(grads[False][off:off + num], grads[True][off:off + num].double())
-        worst = max(worst, e[1])
-        print(f"  {s:32s} {e[0]:.2e} {e[1]:.2e} | {r[0]:.2e} {r[1]:.2e}   {d:.2e}")
-    print(f"  worst new mu error {worst:.3e}")
+        e = rel_l2(g0[off:off + num], st.mu[s].grad)
+        r = rel_l2(g0[eng.P + off:eng.P + off + num], st.rho[s].grad)
+        worst = max(worst, e)
+        print(f"   {s:32s} mu {e:.2e}  rho {r:.2e}")
+    print(f"   worst mu error {worst:.3e}")

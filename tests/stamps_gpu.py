@@ -1,6 +1,6 @@
 """Diagnostic (not a test): phase time stamps of workgroup 0 of one kernel launch of the ELBO step.
 
-usage: python tests/stamps_gpu.py [workload] tag [tag ...]     tag = kind:group, kinds fwd dx dw pdx
+usage: python tests/stamps_gpu.py [workload] tag [tag ...]     tag = kind:group[:workgroup], kinds fwd dx dw pdx
 Phases: fwd  0 top 1 vm-wait 2 B1 3 derived 4 B2 5 mfma 6 reduce 7 epilogue
         dx   0 top 1 vm-wait 2 B1 3 mask 4 B2 5 mfma|issue 6 epilogue
         dw   0 top(loads issued at 1) 1 loads issued 2 barrier 3 staged 4 barrier 5 pooled 6 mfma
@@ -37,7 +37,10 @@ for _ in range(3):
 torch.cuda.synchronize()
 NW = 16
 for tag in args:
-    kind, grp = tag.split(":")
+    parts = tag.split(":")
+    kind, grp = parts[0], parts[1]
+    lib.bnn_debug_stamps_block.argtypes = [C.c_void_p, C.c_int]
+    assert lib.bnn_debug_stamps_block(eng._plan, int(parts[2]) if len(parts) > 2 else 0) == 0
     assert lib.bnn_debug_stamps(eng._plan, KIND[kind] * 16 + int(grp)) == 0
     eng.step(x, y, S, bench.N_DATA, 0.0, wl["prior_scale"], hyp, seed=1)
     torch.cuda.synchronize()
