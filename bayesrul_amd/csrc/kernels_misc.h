@@ -211,7 +211,13 @@ __global__ void prep_weights_kernel(const PrepArgs A) {
   const bool live = e < A.T.P;
   const int lane = threadIdx.x & 63;
   __shared__ double red[8];
+  constexpr int RS_MAX = 128;
+  __shared__ double red_s[RS_MAX];   // radial: per-particle partial sums of this workgroup
   const int radial = (A.mode == 3);
+  if (radial) {
+    for (int k = threadIdx.x; k < RS_MAX; k += blockDim.x) red_s[k] = 0.0;
+    __syncthreads();
+  }
   double kl_local = 0.0;  // mean-field KL contribution of this element
   int si = 0, n = 0, is_bias = 0, bias_idx = 0;
   long fi = 0, ti = 0;
@@ -278,8 +284,17 @@ __global__ void prep_weights_kernel(const PrepArgs A) {
       }
       if (radial) {  // all lanes of the wave take part in the reduction
         const double t = wave_sum_d(term);
-        if (lane == 0) atomicAdd(A.kl_acc + s, t);
+        if (lane == 0) {
+          // one global fp64 atomic per (workgroup, particle) instead of one per wave: S*P/64 atomics on S addresses
+          // used to cost 0.4 ms at S = 20
+          if (s < RS_MAX) atomicAdd(&red_s[s], t);
+          else atomicAdd(A.kl_acc + s, t);
+        }
       }
+    }
+    if (radial) {
+      __syncthreads();
+      for (int s = threadIdx.x; s < A.S && s < RS_MAX; s += blockDim.x) atomicAdd(A.kl_acc + s, red_s[s]);
     }
   }
   if (!radial) {

@@ -1,4 +1,5 @@
 #!/bin/bash
+# bench lines of every workload (quick view; the judged line is `python bench.py`)
 for wl in lrt_linear_s1 lrt_conv_s1 radial_conv_s20 flipout_conv_s10; do
   timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $wl 2>/dev/null | python -c "
 import json,sys
