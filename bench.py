@@ -30,6 +30,11 @@ WORKLOADS = {
                           prior_scale=0.138793, q_scale=0.001351, lr=8.57e-4),
     "lrt_conv_s1": dict(net="inception", guide="normal", fit_context="lrt", S=1, B=1000,
                         prior_scale=0.138793, q_scale=0.001351, lr=8.57e-4),
+    # configs[4]: Flipout-trained Conv BNN, 100-sample predictive pass (tasks/predict.py:24-64, bayesian.py:231-250):
+    # plain Normal sampling, forward only, 10,000 windows per batch (conf/datamodule/ncmapss.yaml:4); a "step" is
+    # one predictive pass over the batch incl. the ep/al variance aggregation
+    "predict_conv_s100": dict(net="inception", guide="normal", fit_context="flipout", S=100, B=10000,
+                              prior_scale=0.198768, q_scale=0.000214, lr=9.48e-4, predict=True, chunk_particles=10),
 }
 N_DATA = 238200
 
@@ -148,8 +153,9 @@ def main():
     if args.batch:
         wl["B"] = args.batch
     S, B = wl["S"], wl["B"]
+    predict = bool(wl.get("predict"))
     eng = SviEngine(net=wl["net"], guide=wl["guide"], fit_context=wl["fit_context"], prec=args.prec, max_particles=S,
-                    max_batch=B, device=dev)
+                    max_batch=B, device=dev, max_windows=wl.get("chunk_particles", 0) * B)
     eng.init_params(mu0_for(wl["net"]), wl["q_scale"])
     xg, yg = synth(B * world)
     x = xg[rank * B:(rank + 1) * B].contiguous().to(dev)
@@ -157,12 +163,14 @@ def main():
     hyp = AdamHyper(lr=wl["lr"], betas=(0.95, 0.999), clip_norm=15.0)
 
     def one_step():
+        if predict:   # windows shard, no collective
+            return eng.predict(x, S, seed=4321, want_samples=False)[0]
         if world > 1:
             return dp_step(eng, x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, rank, world, seed=4321)
         return eng.step(x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, seed=4321)
 
-    ncontr = 2 if wl["fit_context"] in ("lrt", "flipout") else 1
-    em = {"lrt": 1, "flipout": 2}.get(wl["fit_context"], 0)
+    ncontr = 2 if (wl["fit_context"] in ("lrt", "flipout") and not predict) else 1
+    em = 0 if predict else {"lrt": 1, "flipout": 2}.get(wl["fit_context"], 0)
     macs = GROUP_MACS[wl["net"]]
 
     def by_symbol(prof, nsteps):
@@ -218,7 +226,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = float(res[0])
+    loss = float(res[0].flatten()[0]) if predict else float(res[0])   # predict: first aggregated prediction
 
     # separate untimed pass: every launch recorded -> per-kernel table of the report
     npost = min(args.steps, 10)
@@ -251,11 +259,13 @@ def main():
         bytes_launch = bytes_tot / cnt
         kernels = {f"{k[0]}[{k[1]}]": round(v[0] / npost, 4) for k, v in sorted(post.items())}
         out = {
-            "metric": "ELBO-step MC-samples x windows/sec, Conv BNN on N-CMAPSS",
+            "metric": ("predictive-pass MC-samples x windows/sec, Conv BNN on N-CMAPSS" if predict else
+                       "ELBO-step MC-samples x windows/sec, Conv BNN on N-CMAPSS"),
             "value": value, "unit": "MC-samples*windows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
-            "config": {"workload": args.workload, "net": wl["net"], "estimator": wl["fit_context"] or wl["guide"],
+            "config": {"workload": args.workload, "net": wl["net"],
+                       "estimator": "plain-normal predictive" if predict else (wl["fit_context"] or wl["guide"]),
                        "mc_samples": S, "windows_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}", "loss": loss},
             "roofline": {"bound": "mfma", "kernel": sym, "achieved": achieved, "peak": peak,
@@ -268,7 +278,7 @@ def main():
             "kernel_ms_per_step": kernels,   # separate pass with events around every launch
             "kernel_symbols": {f"{k[0]}[{k[1]}]": eng.profile_symbol(*k) for k in sorted(post)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not predict:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out))
     if world > 1:
