@@ -606,12 +606,12 @@ enum { DN_CH = 128, DN_ROWS = 32 };   // dense layers: channels per K chunk, exa
 // ==========================================================================================
 // dense_dx_bf_kernel : dX of a dense layer (K = cout <= 64 is tiny, the output is wide).
 // One workgroup = one 32-row window; dz (= dY [Y>0]) and its second image (LRT: dz*q, Flipout:
-// dz*s_out per row) are staged once into LDS; each of the 16 waves then walks its own 16-channel
-// output tiles independently (weights from L2, no barrier in the tile loop: latency is hidden by
-// the other waves).
+// dz*s_out per row) are staged once into LDS; each of the 8 waves then walks its own 16-channel
+// output tiles in batches of 4 (weights from L2, no barrier in the tile loop).
 // ==========================================================================================
+enum { DDX_WAVES = 8 };   // 8 waves: 256 VGPRs each, room for a batch of 4 tiles' fragments
 template <int EM>
-__global__ __launch_bounds__(1024) void dense_dx_bf_kernel(const GroupArgs A) {
+__global__ __launch_bounds__(DDX_WAVES * 64) void dense_dx_bf_kernel(const GroupArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool DUAL = (EM != EM_PLAIN);
   constexpr bool LRT = (EM == EM_LRT);
@@ -619,9 +619,11 @@ __global__ __launch_bounds__(1024) void dense_dx_bf_kernel(const GroupArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const GroupDesc& G = A.g;
   const BranchDesc& br = G.br[0];
-  const LayerDesc& ly = A.layers[br.layer];
+  const LayerDesc ly = A.layers[br.layer];   // device-resident table: read once, not inside the tile loop
   const Win W = decode_win(G, A.cg, blockIdx.x);
   const int s = W.s;
+  const uint32_t* sgi = A.nz.sign_in + ly.sign_in_off * A.nz.examples + (long)W.ex0 * ly.sign_in_words;   // [row][words]
+  const int sgi_stride = ly.sign_in_words;
   const int zw = (br.cout + 31) & ~31;          // K of the transposed contraction (multiple of 32)
   const int RS = zw + 8;                        // (zw/8 is even) -> conflict-free b128 rows
   u16* dz = (u16*)smem;
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(1024) void dense_dx_bf_kernel(const GroupArgs A) {
   const TensorRef tg = A.t[br.out_t + T_GRAD], ty = A.t[br.out_t], tq = A.t[br.q_t];
   const TensorRef tin = A.t[G.in_t], tdx = A.t[br.dx_t];
   // ---- stage dz / dz2 (4 channels per unit) ----
-  for (int U = tid; U < DN_ROWS * (zw >> 2); U += 1024) {
+  for (int U = tid; U < DN_ROWS * (zw >> 2); U += DDX_WAVES * 64) {
     const int row = U / (zw >> 2), c = (U - row * (zw >> 2)) * 4;
     f32x4 g = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
     if (row < W.nvalid && c < br.cout) {
@@ -677,41 +679,71 @@ __global__ __launch_bounds__(1024) void dense_dx_bf_kernel(const GroupArgs A) {
   const long sa = A.ws.slott_stride_a * s, sb = A.ws.slott_stride_b * s;
   const u16* wat = (const u16*)A.ws.at + sa + ly.wt_off;
   const u16* wbt = (const u16*)A.ws.bt + sb + ly.wt_off;
-  for (int t = wave; t < ntile; t += 16) {
-    const int c0 = t * 16;
-    f32x4 acc_a[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    f32x4 acc_b[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int KPt = ly.KPt;
+  // Tiles in batches of TB: all weight fragments of a batch are fetched first, then its MFMAs and stores.  A
+  // wave that loads and stores shares ONE in-order vmcnt, so the wait for the next batch's fragments also waits
+  // for this batch's stores; paying that round trip once per TB tiles instead of once per tile is the point.
+  constexpr int TB = 4;
+  for (int t0 = wave; t0 < ntile; t0 += DDX_WAVES * TB) {
+    bf16x8 wa[TB][2], wb[TB][2];
+    uint32_t sw[TB][2];   // flipout: sign_in word of (row, 4 channels of this lane), per m-tile
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (ks < nks) {
-        const long wo = (long)(c0 + i16) * ly.KPt + br.n_off + ks * 32 + g4 * 8;
-        const bf16x8 wa = *(const bf16x8*)(wat + wo);
+    for (int j = 0; j < TB; ++j) {
+      const int t = t0 + DDX_WAVES * j;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bz[ks][mt], acc_a[mt], 0, 0, 0);
-        if constexpr (DUAL) {
-          const bf16x8 wb = *(const bf16x8*)(wbt + wo);
+      for (int ks = 0; ks < 2; ++ks) {
+        wa[j][ks] = wb[j][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < ntile && ks < nks) {
+          const long wo = (long)(t * 16 + i16) * KPt + br.n_off + ks * 32 + g4 * 8;
+          wa[j][ks] = *(const bf16x8*)(wat + wo);
+          if constexpr (DUAL) wb[j][ks] = *(const bf16x8*)(wbt + wo);
+        }
+      }
+      if constexpr (EM == EM_FLIPOUT) {
+        const int och = t * 16 + 4 * g4;
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, bz2[ks][mt], acc_b[mt], 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) {
+          const int row = min(mt * 16 + i16, W.nvalid - 1);
+          sw[j][mt] = 0u;
+          if (t < ntile) sw[j][mt] = sgi[(long)row * sgi_stride + (och >> 5)] >> (och & 31);
         }
       }
     }
-    const int och = c0 + 4 * g4;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int row = mt * 16 + i16;
-      if (row >= W.nvalid) continue;
-      f32x4 v = acc_a[mt];
-      if constexpr (LRT) {
-        f32x4 xv = tload4(tin, (long)(W.in_row0 + row) * tin.ctot + br.in_off + och, 4, true);
+    for (int j = 0; j < TB; ++j) {
+      const int t = t0 + DDX_WAVES * j;
+      if (t >= ntile) break;
+      const int c0 = t * 16;
+      f32x4 acc_a[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      f32x4 acc_b[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += 2.f * bf2f(f2bf(xv[r])) * acc_b[mt][r];
-      } else if constexpr (EM == EM_FLIPOUT) {
-        const uint32_t word = A.nz.sign_in[ly.sign_in_off * A.nz.examples + (long)(W.ex0 + row) * ly.sign_in_words + (och >> 5)];
-        const uint32_t bits = word >> (och & 31);
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks < nks) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += ((bits >> r) & 1u) ? -acc_b[mt][r] : acc_b[mt][r];
+          for (int mt = 0; mt < 2; ++mt) acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j][ks], bz[ks][mt], acc_a[mt], 0, 0, 0);
+          if constexpr (DUAL) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[j][ks], bz2[ks][mt], acc_b[mt], 0, 0, 0);
+          }
+        }
       }
-      tstore4(tdx, (long)(W.in_row0 + row) * tdx.ctot + br.in_off + och, v, 4, true);
+      const int och = c0 + 4 * g4;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 16 + i16;
+        if (row >= W.nvalid) continue;
+        f32x4 v = acc_a[mt];
+        if constexpr (LRT) {
+          f32x4 xv = tload4(tin, (long)(W.in_row0 + row) * tin.ctot + br.in_off + och, 4, true);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += 2.f * bf2f(f2bf(xv[r])) * acc_b[mt][r];
+        } else if constexpr (EM == EM_FLIPOUT) {
+          const uint32_t bits = sw[j][mt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += ((bits >> r) & 1u) ? -acc_b[mt][r] : acc_b[mt][r];
+        }
+        tstore4(tdx, (long)(W.in_row0 + row) * tdx.ctot + br.in_off + och, v, 4, true);
+      }
     }
   }
 }

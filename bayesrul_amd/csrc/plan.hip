@@ -1220,9 +1220,9 @@ static int launch_dense_dx_bf(const GroupArgs& A0, int em, hipStream_t st, Prof*
   const unsigned grid = (unsigned)A.cg.nwin;
   ProfScope ps_(pf, PK_DX, gi, st);
   ps_.name("dense_dx_bf_kernel<%d>", em);
-  if (em == EM_PLAIN) dense_dx_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(1024), lds, st>>>(A);
-  else if (em == EM_LRT) dense_dx_bf_kernel<EM_LRT><<<dim3(grid), dim3(1024), lds, st>>>(A);
-  else dense_dx_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(1024), lds, st>>>(A);
+  if (em == EM_PLAIN) dense_dx_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(DDX_WAVES * 64), lds, st>>>(A);
+  else if (em == EM_LRT) dense_dx_bf_kernel<EM_LRT><<<dim3(grid), dim3(DDX_WAVES * 64), lds, st>>>(A);
+  else dense_dx_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DDX_WAVES * 64), lds, st>>>(A);
   HIP_TRY(hipGetLastError());
   return 0;
 }
