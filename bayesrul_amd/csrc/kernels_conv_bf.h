@@ -1103,8 +1103,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs 
       }
     }
   };
-  // 11 tiles per wave leave no registers for the early loads (they would spill): load at the top instead
-  constexpr bool PF = MAXT < 11;
+  // 11 tiles per wave leave no registers for the early loads of TWO windows (they would spill): one window per
+  // iteration there, or the loads at the top
+  constexpr bool PF = MAXT < 11 || NWI == 1;
   if (PF && my_nwin > 0) load_iter(0);
   for (int k0 = 0; k0 < my_nwin; k0 += NWI) {
     const int nw = min(NWI, my_nwin - k0);

@@ -1028,7 +1028,9 @@ static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int e
   // windows per iteration: bounded by LDS and by the registers that hold an iteration's loads
   // (variants that would spill are avoided: measured with -Rpass-analysis)
   const int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
-  int nwi = lrt ? (tpw > 6 ? 1 : 2) : (tpw > 6 ? 2 : (em == EM_FLIPOUT ? 2 : 4));
+  // windows per iteration: one (with the next window's loads in flight) where 11 tiles per wave fill the registers
+  int nwi = lrt ? (tpw > 6 ? 1 : 2) : (tpw > 6 ? 1 : (em == EM_FLIPOUT ? 2 : 4));
+  if (const char* e = getenv("BNN_DW_NWI")) nwi = atoi(e);   // experiments only (1, 2 or 4)
   while (nwi > 1 && nwi * wbytes > 160 * 1024) nwi /= 2;
   if (nwi * wbytes > 160 * 1024) return fail(BNN_E_INVALID, "conv dW: %d bytes of LDS per window", wbytes);
   const int lds = nwi * wbytes;
