@@ -923,8 +923,9 @@ __global__ __launch_bounds__(512) void dense_dw_bf_kernel(const GroupArgs A, int
 // units straight from the bf16 planes), so the memory pipe sees NWI windows of traffic at once.
 // Tiles (all branches of the group) stay in registers across the windows of the workgroup.
 // ==========================================================================================
-template <int EM, int MAXT, int NWI>
-__global__ __launch_bounds__(CV_THREADS) void conv_dw_mw_kernel(const GroupArgs A, const ConvDwPlan D) {
+template <int EM, int MAXT, int NWI, int NWV>
+__global__ __launch_bounds__(NWV * 64) void conv_dw_mw_kernel(const GroupArgs A, const ConvDwPlan D) {
+  constexpr int CV_THREADS = NWV * 64, CV_WAVES = NWV;   // shadows the 8-wave defaults
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool DUAL = (EM != EM_PLAIN);
   constexpr bool LRT = (EM == EM_LRT);

@@ -994,17 +994,24 @@ static void build_conv_dw_plan(const GroupArgs& A, const LayerDesc* layers, Conv
 }
 
 template <int EM, int NWI>
-static int launch_conv_dw_mw_em(const GroupArgs& A, const ConvDwPlan& D, int lds, unsigned grid, hipStream_t st) {
-  const int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
-  if (tpw <= 4) {
-    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 4, NWI>, lds));
-    conv_dw_mw_kernel<EM, 4, NWI><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+static int launch_conv_dw_mw_em(const GroupArgs& A, const ConvDwPlan& D, int lds, unsigned grid, int nwv, hipStream_t st) {
+  const int tpw = (D.ntiles + nwv - 1) / nwv;
+  if (nwv == 16) {   // 16-wave workgroups: at most 6 tiles per wave, one window per iteration
+    if constexpr (NWI == 1) {
+      BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 6, 1, 16>, lds));
+      conv_dw_mw_kernel<EM, 6, 1, 16><<<dim3(grid), dim3(1024), lds, st>>>(A, D);
+    } else {
+      return fail(BNN_E_INVALID, "conv dW: 16-wave variant is single-window");
+    }
+  } else if (tpw <= 4) {
+    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 4, NWI, 8>, lds));
+    conv_dw_mw_kernel<EM, 4, NWI, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
   } else if (tpw <= 6) {
-    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 6, NWI>, lds));
-    conv_dw_mw_kernel<EM, 6, NWI><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 6, NWI, 8>, lds));
+    conv_dw_mw_kernel<EM, 6, NWI, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
   } else {
-    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 11, NWI>, lds));
-    conv_dw_mw_kernel<EM, 11, NWI><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 11, NWI, 8>, lds));
+    conv_dw_mw_kernel<EM, 11, NWI, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1024,22 +1031,28 @@ static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int e
   const int xbytes = (IMG_ROWS * img_row_stride(xw16, true) * 2 + 15) & ~15;
   const int zbytes = (IMG_ROWS * img_row_stride(D.zw, true) * 2 + 15) & ~15;
   const bool lrt = em == EM_LRT;
-  const int wbytes = xbytes + (D.has_pool ? xbytes : 0) + zbytes + (lrt ? xbytes + (D.has_pool ? xbytes : 0) + zbytes : 0);
+  const int wbytes = xbytes + (D.has_pool ? xbytes : 0) + zbytes + (lrt ? xbytes + (D.has_pool ? xbytes : 0) + zbytes : 0) +
+                     (em == EM_FLIPOUT ? 128 : 0);
   // windows per iteration: bounded by LDS and by the registers that hold an iteration's loads
   // (variants that would spill are avoided: measured with -Rpass-analysis)
-  const int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
-  // windows per iteration: one (with the next window's loads in flight) where 11 tiles per wave fill the registers
-  int nwi = lrt ? (tpw > 6 ? 1 : 2) : (tpw > 6 ? 1 : (em == EM_FLIPOUT ? 2 : 4));
-  if (const char* e = getenv("BNN_DW_NWI")) nwi = atoi(e);   // experiments only (1, 2 or 4)
+  int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
+  // more than 6 tiles per wave: 16-wave workgroups (<= 6 tiles each), one window per iteration with the next
+  // window's loads in flight
+  // (plain contraction only: the Flipout / LRT variants of that shape need more than the 128 registers of a
+  // 16-wave workgroup)
+  int nwv = (tpw > 6 && em == EM_PLAIN && !getenv("BNN_DW_8WAVES")) ? 16 : 8;
+  if (nwv == 16) tpw = (D.ntiles + 15) / 16;
+  int nwi = lrt ? (tpw > 6 ? 1 : 2) : (nwv == 16 || tpw > 6 ? 1 : (em == EM_FLIPOUT ? 2 : 4));
+  if (const char* e = getenv("BNN_DW_NWI")) nwi = nwv == 16 ? 1 : atoi(e);   // experiments only (1, 2 or 4)
   while (nwi > 1 && nwi * wbytes > 160 * 1024) nwi /= 2;
   if (nwi * wbytes > 160 * 1024) return fail(BNN_E_INVALID, "conv dW: %d bytes of LDS per window", wbytes);
   const int lds = nwi * wbytes;
   const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
   ProfScope ps_(pf, PK_DW, gi, st);
-  ps_.name("conv_dw_mw_kernel<%d, %d, %d>", em, tpw <= 4 ? 4 : (tpw <= 6 ? 6 : 11), nwi);
-#define DISPATCH_NWI(EMV)                                                            \
-  (nwi == 4 ? launch_conv_dw_mw_em<EMV, 4>(A, D, lds, grid, st)                      \
-            : (nwi == 2 ? launch_conv_dw_mw_em<EMV, 2>(A, D, lds, grid, st) : launch_conv_dw_mw_em<EMV, 1>(A, D, lds, grid, st)))
+  ps_.name("conv_dw_mw_kernel<%d, %d, %d, %d>", em, nwv == 16 ? 6 : (tpw <= 4 ? 4 : (tpw <= 6 ? 6 : 11)), nwi, nwv);
+#define DISPATCH_NWI(EMV)                                                                 \
+  (nwi == 4 ? launch_conv_dw_mw_em<EMV, 4>(A, D, lds, grid, nwv, st)                      \
+            : (nwi == 2 ? launch_conv_dw_mw_em<EMV, 2>(A, D, lds, grid, nwv, st) : launch_conv_dw_mw_em<EMV, 1>(A, D, lds, grid, nwv, st)))
   if (em == EM_PLAIN) return DISPATCH_NWI(EM_PLAIN);
   if (em == EM_LRT) return DISPATCH_NWI(EM_LRT);
   return DISPATCH_NWI(EM_FLIPOUT);
