@@ -23,7 +23,7 @@
 //             (sign-bit XOR), so every branch accumulates into one accumulator.
 #pragma once
 
-enum { DX2_KS = 6, DX2_MAXI = 48, DX2_NC = 4, DX2_NL = 2, DX2_NW = DX2_NC + DX2_NL, DX2_LI = DX2_MAXI / DX2_NL, DX2_MU = 2 };   // DX2_KS >= KD + KP of every instantiation
+enum { DX2_KS = 6, DX2_MAXI = 48, DX2_NL = 2, DX2_LI = DX2_MAXI / DX2_NL, DX2_MU = 2 };   // DX2_KS >= KD + KP of every instantiation
 
 struct Dx2Inst {          // one LDS-DMA instruction of a window (64 lanes x 16 bytes), host-resolved
   const void* base;       // plane base + first channel of the stream
@@ -103,8 +103,11 @@ struct ConvDx2Plan {
     }                                                                   \
   } while (0)
 
-template <int EM, int KD, int KP>
-__global__ __launch_bounds__(DX2_NW * 64) void conv_dx2_kernel(const GroupArgs A, const ConvDx2Plan D) {
+// NC compute waves (tiles per workgroup kind): 4 -> two kinds, two workgroups per CU; 8 -> one kind, one workgroup
+// per CU that loads and masks every dY / Y slice once
+template <int EM, int KD, int KP, int NC>
+__global__ __launch_bounds__((NC + DX2_NL) * 64) void conv_dx2_kernel(const GroupArgs A, const ConvDx2Plan D) {
+  constexpr int DX2_NC = NC, DX2_NW = NC + DX2_NL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool DUAL = (EM != EM_PLAIN);
   constexpr bool LRT = (EM == EM_LRT);

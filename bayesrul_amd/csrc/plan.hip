@@ -1084,7 +1084,10 @@ static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em,
   const int L = A.g.L, xw = A.g.in_cin_p;
   const int npt = em == EM_LRT ? 3 : 2;
   D.ntile = xw / 16;
-  D.nkinds = (D.ntile + DX2_NC - 1) / DX2_NC;
+  // 8 tiles: one 10-wave workgroup kind (every slice loaded and masked once) unless BNN_DX_NC4 asks for two 6-wave kinds
+  const int nc = (D.ntile > 4 && !getenv("BNN_DX_NC4")) ? 8 : 4;
+  const int nw = nc + DX2_NL;
+  D.nkinds = (D.ntile + nc - 1) / nc;
   int zel = 0, units = 0;
   int nkd = 0, nkp = 0;   // k-steps of the direct / pooled branches
   signed char kb[2][DX2_KS], ki[2][DX2_KS];
@@ -1115,7 +1118,7 @@ static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em,
   for (int i = 0; i < nkd; ++i) { D.ks_b[i] = kb[0][i]; D.ks_i[i] = ki[0][i]; }
   for (int i = 0; i < nkp; ++i) { D.ks_b[5 + i] = kb[1][i]; D.ks_i[5 + i] = ki[1][i]; }
   if (nks == 0) return 0;
-  if (units > DX2_MU * DX2_NW * 64) return fail(BNN_E_INVALID, "conv dX: mask pass needs %d units", units);
+  if (units > DX2_MU * nw * 64) return fail(BNN_E_INVALID, "conv dX: mask pass needs %d units", units);
   if (D.has_pool && (!A.amax || (xw % 16) != 0 || ((xw / 16) & (xw / 16 - 1)) != 0))
     return fail(BNN_E_INVALID, "conv dX: pooled branch without an arg-max plane");
   if ((xw / 8) & (xw / 8 - 1)) return fail(BNN_E_INVALID, "conv dX: %d input channels", xw);
@@ -1164,7 +1167,10 @@ static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em,
   const int extra = 4096;
   auto total = [&](int ns) { return ns * D.slot_bytes + ns * 256 + extra; };
   int wg_per_cu = 2;
-  if (total(3) <= 80 * 1024) D.nslots = 3;
+  if (nc == 8) {   // 10 waves of ~146 registers: one workgroup per CU
+    wg_per_cu = 1;
+    D.nslots = total(3) <= 160 * 1024 ? 3 : 2;
+  } else if (total(3) <= 80 * 1024) D.nslots = 3;
   else if (total(2) <= 80 * 1024) D.nslots = 2;
   else {
     wg_per_cu = 1;
@@ -1175,11 +1181,16 @@ static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em,
   D.nsplit = std::max(1, std::min(A.cg.B, (256 * wg_per_cu) / std::max(1, A.cg.S * D.nkinds)));
   const unsigned grid = (unsigned)(A.cg.S * D.nsplit * D.nkinds);
   ProfScope ps_(pf, PK_DX, gi, st);
-  ps_.name("conv_dx2_kernel<%d, 5, %d>", em, nkp);
+  ps_.name("conv_dx2_kernel<%d, 5, %d, %d>", em, nkp, nc);
 #define LAUNCH_DX2(EMV, KPV)                                                                   \
   do {                                                                                         \
-    BNN_TRY(set_lds(conv_dx2_kernel<EMV, 5, KPV>, lds));                                       \
-    conv_dx2_kernel<EMV, 5, KPV><<<dim3(grid), dim3(DX2_NW * 64), lds, st>>>(A, D);            \
+    if (nc == 8) {                                                                             \
+      BNN_TRY(set_lds(conv_dx2_kernel<EMV, 5, KPV, 8>, lds));                                  \
+      conv_dx2_kernel<EMV, 5, KPV, 8><<<dim3(grid), dim3(nw * 64), lds, st>>>(A, D);           \
+    } else {                                                                                   \
+      BNN_TRY(set_lds(conv_dx2_kernel<EMV, 5, KPV, 4>, lds));                                  \
+      conv_dx2_kernel<EMV, 5, KPV, 4><<<dim3(grid), dim3(nw * 64), lds, st>>>(A, D);           \
+    }                                                                                          \
   } while (0)
   if (em == EM_PLAIN) {
     if (nkp) LAUNCH_DX2(EM_PLAIN, 1); else LAUNCH_DX2(EM_PLAIN, 0);
