@@ -1079,7 +1079,16 @@ __global__ __launch_bounds__(NWV * 64) void conv_dw_mw_kernel(const GroupArgs A,
   // stores, so their latency hides behind the pooled-copy pass and the MFMA phase
   uint4 px[NWI], pz[NWI][2], py[NWI][2], pq[NWI][2];
   uint32_t psg[NWI];
-  auto load_iter = [&](int k0) {
+  // running element offsets of window k0 of this workgroup (advanced by NWI windows per call): the loads of an
+  // iteration cost a handful of adds, not 64-bit multiplies per pointer (1,400 cycles per call before)
+  const long w_first = (long)s * B + split;
+  long o_x = (G.in_bcast ? (long)split : w_first) * L * tin.ctot + x_src;
+  const long st_x = (long)D.nsplit * L * tin.ctot;
+  long o_z[2] = {w_first * L * z_ct[0] + z_src[0], w_first * L * z_ct[1] + z_src[1]};
+  const long st_z[2] = {(long)D.nsplit * L * z_ct[0], (long)D.nsplit * L * z_ct[1]};
+  long r_sg = w_first * sg_stride;
+  const long st_sg = (long)D.nsplit * sg_stride;
+  auto load_iter = [&](int k0) {   // must be called for k0 = 0, NWI, 2 NWI, ... in order
     const int nw = min(NWI, my_nwin - k0);
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
@@ -1088,21 +1097,22 @@ __global__ __launch_bounds__(NWV * 64) void conv_dw_mw_kernel(const GroupArgs A,
 #pragma unroll
       for (int u = 0; u < 2; ++u) pz[i][u] = py[i][u] = pq[i][u] = make_uint4(0, 0, 0, 0);
       if (i < nw && !(A.pool_sel & 8)) {
-        const int wl = split + (k0 + i) * D.nsplit;
-        const long w = (long)s * B + wl;
-        const long xrow0 = (G.in_bcast ? wl : w) * L;
-        if (x_on) px[i] = *(const uint4*)(g_x + xrow0 * tin.ctot + x_src);
-        if (sg_src) psg[i] = sg_src[w * sg_stride];
+        if (x_on) px[i] = *(const uint4*)(g_x + o_x + i * st_x);
+        if (sg_src) psg[i] = sg_src[r_sg + i * st_sg];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           if (z_g[u]) {
-            const long o = w * L * z_ct[u] + z_src[u];
+            const long o = o_z[u] + i * st_z[u];
             pz[i][u] = *(const uint4*)(z_g[u] + o);
             if (z_y[u]) py[i][u] = *(const uint4*)(z_y[u] + o);
             if constexpr (LRT) pq[i][u] = *(const uint4*)(z_q[u] + o);
           }
       }
     }
+    o_x += NWI * st_x;
+    r_sg += NWI * st_sg;
+    o_z[0] += NWI * st_z[0];
+    o_z[1] += NWI * st_z[1];
   };
   // 11 tiles per wave leave no registers for the early loads of TWO windows (they would spill): one window per
   // iteration there, or the loads at the top
@@ -1114,7 +1124,7 @@ __global__ __launch_bounds__(NWV * 64) void conv_dw_mw_kernel(const GroupArgs A,
     stamp(kst, 0);
     if (!PF) load_iter(k0);
     stamp(kst, 1);
-    __syncthreads();   // previous iteration's images consumed
+    lds_barrier();   // raw s_barrier: __syncthreads() would also drain the prefetched global loads (vmcnt(0))   // previous iteration's images consumed
     stamp(kst, 2);
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
@@ -1139,7 +1149,7 @@ __global__ __launch_bounds__(NWV * 64) void conv_dw_mw_kernel(const GroupArgs A,
     }
     stamp(kst, 3);
     if (PF && k0 + NWI < my_nwin) load_iter(k0 + NWI);
-    __syncthreads();
+    lds_barrier();   // raw s_barrier: __syncthreads() would also drain the prefetched global loads (vmcnt(0))
     stamp(kst, 4);
     if (D.has_pool && !(A.pool_sel & 2)) {
 #pragma unroll
@@ -1153,7 +1163,7 @@ __global__ __launch_bounds__(NWV * 64) void conv_dw_mw_kernel(const GroupArgs A,
           if constexpr (LRT) *(uint4*)&base[(o_xpsq >> 1) + x_dst] = sq8(m);
         }
       }
-      __syncthreads();
+      lds_barrier();   // raw s_barrier: __syncthreads() would also drain the prefetched global loads (vmcnt(0))
     }
     stamp(kst, 5);
     // ---- tiles ----
