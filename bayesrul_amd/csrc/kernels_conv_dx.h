@@ -47,6 +47,12 @@ struct ConvDx2Plan {
   Dx2Inst inst[DX2_MAXI];
 };
 
+// value of the lane `rotation` positions away inside the 16-lane DPP row (one VALU move, no LDS crossbar)
+template <int CTRL>
+__device__ __forceinline__ float rot16(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
 #define BNN_WAIT_VMCNT_WIDE(N)                                          \
   do {                                                                  \
     switch (N) {                                                        \
@@ -339,7 +345,6 @@ __global__ __launch_bounds__((NC + DX2_NL) * 64) void conv_dx2_kernel(const Grou
     }
   }
   const int och = ct * 16 + 4 * g4;   // channel of the target tensor held by this lane
-  const int lane_prev = (lane & 48) | ((i16 - 1) & 15), lane_next = (lane & 48) | ((i16 + 1) & 15);
   const int zel = D.zelems;
 
   __syncthreads();   // zero fill + table visible
@@ -442,8 +447,9 @@ __global__ __launch_bounds__((NC + DX2_NL) * 64) void conv_dx2_kernel(const Grou
         // (i16) and in the two m-tiles
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float a0 = __shfl(dn[0][r], lane_prev, 64), a1 = __shfl(dn[1][r], lane_prev, 64);
-          const float b0 = __shfl(up[0][r], lane_next, 64), b1 = __shfl(up[1][r], lane_next, 64);
+          // DPP row rotations (rows = the 16 lanes of a lane group): ror:1 reads lane i16-1, ror:15 lane i16+1 (mod 16)
+          const float a0 = rot16<0x121>(dn[0][r]), a1 = rot16<0x121>(dn[1][r]);
+          const float b0 = rot16<0x12F>(up[0][r]), b1 = rot16<0x12F>(up[1][r]);
           v[0][r] += (i16 == 0 ? 0.f : a0) + (i16 == 15 ? b1 : b0);
           v[1][r] += (i16 == 0 ? a0 : a1) + (i16 == 15 ? 0.f : b1);
         }
