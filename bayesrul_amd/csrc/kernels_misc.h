@@ -569,3 +569,22 @@ __global__ void predict_finish_kernel(const float* preds /*[S][B][2]*/, int B, i
   out4[2 * B + b] = ep;
   out4[3 * B + b] = al;
 }
+
+// ------------------------------------------------------------------------------------------
+// window store: gather a batch of windows by index from an HBM-resident set.
+// feature_major = 1: a stored window is the reference's LMDB value, [F][W] fp32 (data/lmdb_utils.py:190-191 reads
+// it with reshape(n_features, -1).T), and is transposed to the [W][F] the step consumes.
+// ------------------------------------------------------------------------------------------
+__global__ void gather_windows_kernel(const float* x_all, const float* y_all, const long* idx, long n, int W, int F,
+                                      int feature_major, float* x_out, float* y_out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int wf = W * F;
+  if (e >= n * wf) return;
+  const long i = e / wf;
+  const int r = (int)(e - i * wf);
+  const long j = idx[i];
+  const int w = r / F, f = r - w * F;
+  x_out[e] = x_all[j * wf + (feature_major ? f * W + w : r)];
+  if (r == 0 && y_all) y_out[i] = y_all[j];
+}
+

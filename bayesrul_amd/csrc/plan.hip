@@ -1620,6 +1620,21 @@ extern "C" int bnn_profile_enable(BnnPlan* p, int on) {
   return 0;
 }
 
+// window store (data feed): x_out[i] = window idx[i] of an HBM-resident set, y_out[i] = its label.  Replaces the
+// per-item reads of LmdbDataset.__getitem__ (data/lmdb_utils.py:184-194) + NCMAPSSLmdbDataset.__getitem__
+// (data/ncmapss/dataset.py:13-16) + the DataLoader collate for a whole batch.
+extern "C" int bnn_gather_windows(const float* x_all, const float* y_all, const int64_t* idx, int64_t n, int32_t win_length,
+                                  int32_t n_features, int32_t feature_major, float* x_out, float* y_out, void* stream) {
+  if (n < 0 || win_length <= 0 || n_features <= 0) return fail(BNN_E_INVALID, "bad geometry");
+  if (n == 0) return 0;   // an empty batch carries no buffers
+  if (!x_all || !idx || !x_out || (y_all && !y_out)) return fail(BNN_E_INVALID, "null argument");
+  const long total = (long)n * win_length * n_features;
+  gather_windows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+      x_all, y_all, (const long*)idx, (long)n, win_length, n_features, feature_major, x_out, y_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // Restricts the recorder to the given tags (n = 0: every launch).  Two events per recorded launch sit
 // between the kernels on the stream, so bench.py's timed region records the dominant symbol only.
 extern "C" int bnn_profile_select(BnnPlan* p, const int32_t* tags, int32_t n) {

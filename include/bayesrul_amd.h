@@ -179,6 +179,14 @@ int bnn_export_noise(BnnPlan* plan, const BnnElboArgs* a, uint64_t seed, uint64_
                      float* radial_r, float* const* lrt_eps, float* const* sign_in, float* const* sign_out,
                      void* stream);
 
+/* ---- window store: batch gather from an HBM-resident window set ----
+ * Replaces LmdbDataset.__getitem__ (bayesrul/data/lmdb_utils.py:184-194), NCMAPSSLmdbDataset.__getitem__
+ * (bayesrul/data/ncmapss/dataset.py:13-16) and the DataLoader collate: x_out[i] = window idx[i], y_out[i] = its RUL.
+ * feature_major != 0: stored windows are the reference's LMDB values, [n_features][win_length] fp32, and are
+ * transposed to [win_length][n_features] (lmdb_utils.py:190-191).  y_all / y_out may be NULL.  Device pointers. */
+int bnn_gather_windows(const float* x_all, const float* y_all, const int64_t* idx, int64_t n, int32_t win_length,
+                       int32_t n_features, int32_t feature_major, float* x_out, float* y_out, void* stream);
+
 /* ---- measurement: per-kernel durations from HIP events recorded on the launch stream ----
  * tag = kind * 16 + group; kind: 0 group forward, 1 group dX, 2 group dW, 3 weight sampling,
  * 4 head/NLL, 5 gradient finalize, 6 ClippedAdam, 7 max-pool backward. */
