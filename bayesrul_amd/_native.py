@@ -78,6 +78,15 @@ def load() -> C.CDLL:
         raise NativeError(
             f"{LIB_PATH} not found: build it with `python -m bayesrul_amd.csrc.build` "
             "(or __graft_entry__.build()). There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own HIP runtime, the library links the system one: when the system runtime is
+    # mapped first and torch's initialises first, the library's later hipGetDevice finds no device.  Bring torch's
+    # runtime up before the library is mapped (a no-op on a box without a GPU).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:  # pragma: no cover - torch is the memory / stream provider of this package
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.bnn_last_error.restype = C.c_char_p
     lib.bnn_abi_sizeof.restype = C.c_size_t
