@@ -755,7 +755,7 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
   A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), nullptr, 128, p->d.prec == BNN_PREC_BF16X3 ? TF_BF16 : TF_F32};
   A->amax = nullptr;
   A->dbg_block = p->dbg_block;
-  if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION)
+  if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION && c->train)   // no backward, no codes (evaluate / predict)
     for (int b = 0; b < A->g.n_branch; ++b)
       if (A->g.br[b].pool && A->g.br[b].dx_t >= 0) A->amax = (unsigned char*)w + p->o_amax;
   A->layers = (const LayerDesc*)(w + p->o_layers);
