@@ -59,11 +59,16 @@ __global__ __launch_bounds__(256) void group_fwd_kernel(const GroupArgs A) {
   typename P::elem* x1 = P::BF ? L.img[1] : nullptr;
   typename P::elem* x2 = P::BF ? L.img[2] : L.img[1];
 
-  for (int win = blockIdx.x * nwaves + wave; win < A.cg.nwin; win += gridDim.x * nwaves) {
+  // work item = (window, branch): a dense group of the Linear net has only B/32 windows per particle, so the
+  // branches of a window go to different waves (each stages the window chunk it needs itself)
+  const int nitem = A.cg.nwin * G.n_branch;
+  for (int item = blockIdx.x * nwaves + wave; item < nitem; item += gridDim.x * nwaves) {
+    const int win = item / G.n_branch;
     const Win W = decode_win(G, A.cg, win);
     const TensorRef tin = A.t[G.in_t];
     int staged_off = -1, staged_pool = -1, staged_c0 = -1;
-    for (int b = 0; b < G.n_branch; ++b) {
+    {
+      const int b = item - win * G.n_branch;
       const BranchDesc& br = G.br[b];
       const LayerDesc& ly = A.layers[br.layer];
       f32x4 acc_a[4][2], acc_b[4][2];

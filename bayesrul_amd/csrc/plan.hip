@@ -781,7 +781,7 @@ static int launch_fwd(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int
   const int nimg = P::BF ? 3 : 2;
   A.lds_per_wave = nimg * img_bytes(DENSE_CHUNK, P::BF);
   const int lds = 4 * A.lds_per_wave;
-  const unsigned grid = (unsigned)std::min((A.cg.nwin + 3) / 4, 2048);
+  const unsigned grid = (unsigned)std::min((A.cg.nwin * A.g.n_branch + 3) / 4, 2048);   // items = (window, branch)
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(group_fwd_kernel<P, EM_PLAIN>, lds));
     group_fwd_kernel<P, EM_PLAIN><<<dim3(grid), dim3(256), lds, st>>>(A);
