@@ -194,6 +194,32 @@ def test_predictive_pass_matches_oracle(guide):
     assert torch.allclose(o[3], ref["al_vars"], rtol=1e-4, atol=1e-6)
 
 
+def test_predict_and_validation_bf16x3_agree_with_f32():
+    """The bf16x3 kernels on the no-gradient paths (plain sampling: tasks.predict and validation_step): same Philox
+    noise through an f32 and a bf16x3 engine; predict walks the particles in chunks of two."""
+    S, B = 6, 70
+    ps, qs, lr = HYP["flipout"]
+    from bayesrul_amd import _native as N
+    from bayesrul_amd.engine import SviEngine
+    mu0 = R.init_mu0("inception", 0, torch.float64)
+    x, y = synth_batch(B)
+    out = {}
+    for prec in ("f32", "bf16x3"):
+        eng = SviEngine(net="inception", guide="normal", fit_context="flipout", prec=prec, max_particles=S, max_batch=B,
+                        max_windows=2 * B)   # predict walks the particles in chunks (the Philox stream depends on the chunking)
+        eng.init_params(mu0, qs * 20)
+        o4, samples = eng.predict(x.cuda(), S, seed=5)
+        eng = SviEngine(net="inception", guide="normal", fit_context="flipout", prec=prec, max_particles=S, max_batch=B)
+        eng.init_params(mu0, qs * 20)
+        res = eng.evaluate(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, mode=N.MODE_NORMAL, seed=7)
+        out[prec] = (o4.cpu().double(), samples.cpu().double(), float(res[0]))
+    a, b = out["f32"], out["bf16x3"]
+    assert torch.allclose(b[1], a[1], rtol=2e-3, atol=1e-4)          # per-particle predictions
+    assert torch.allclose(b[0][0], a[0][0], rtol=1e-3, atol=1e-4)    # aggregated mean
+    assert torch.allclose(b[0][1], a[0][1], rtol=5e-3, atol=1e-4)    # total std
+    assert abs(b[2] - a[2]) <= 2e-4 * abs(a[2])                       # validation ELBO
+
+
 def test_ragged_and_single_window_batches():
     """B = 1 (one window) and B = 33 (dense chunk of 32 + 1) keep parity (edge cases)."""
     for B in (1, 33):
