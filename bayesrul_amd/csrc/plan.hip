@@ -874,9 +874,12 @@ static int build_conv_fwd2_jobs(const GroupArgs& A, const LayerDesc* layers, uns
   // optional splits only where a K-split reduction (one more barrier per window) is needed anyway
   bool any_split = false;
   for (const Tile& t : tiles) any_split |= t.nm > 1;
+  // keep splitting the longest job while it has more than 2 k-steps (measured optimum on the block-2 k3/k5 group:
+  // finer splits cost more in the LDS reduction than they save in MFMAs); BNN_FWD_FILL overrides for experiments
+  const double fill_thr = getenv("BNN_FWD_FILL") ? atof(getenv("BNN_FWD_FILL")) : 2.0;
   while (any_split && njobs < nc) {
     int best = -1;
-    double bv = 1.0;
+    double bv = fill_thr;
     for (size_t t = 0; t < tiles.size(); ++t) {
       const double v = (double)tiles[t].ks / tiles[t].nm;
       if (v > bv && tiles[t].nm < tiles[t].ks) { bv = v; best = (int)t; }
