@@ -1,0 +1,424 @@
+// trunk_fwd_kernel : the whole convolutional trunk of the Inception net (nets/inception.py:10-132: both
+// inception blocks, 10 variational Conv1d layers) as ONE launch.  bf16 hi/lo planes, gfx950.
+//
+// One workgroup owns a particle and walks the windows split, split + nsplit, ...; a window flows through a
+// three-stage software pipeline inside the workgroup, one stage per step, ONE barrier per step:
+//     step t :  loader  : window t+1's x planes (regs -> LDS), window t+2's global loads issued
+//               stage 0 : block 1 (4 branches, x -> ACT1 + its MaxPool1d(3,1,1) copy)         window t
+//               stage 1 : block 2, 1x1 level (ACT1 -> MID, ACT2 channels 0..15, 48..79)       window t-1
+//               stage 2 : block 2, k3 / k5 level (MID -> ACT2 channels 16..47)                window t-2
+// Every inter-stage image lives in LDS only (double-buffered by window parity): ACT1, its pooled copy and MID
+// never reach HBM as operands of this pass.  What IS written to HBM: ACT2 (hi + lo planes, the dense layer's
+// input) and, for a training step, the hi planes of ACT1 / MID and the arg-max codes the backward kernels read.
+//
+// 11 compute waves + 1 loader wave; every compute wave owns a fixed set of (layer, n-tile) jobs whose weight
+// fragments (mean hi / lo, Flipout dW) stay in registers for the whole launch.  The jobs are dealt so that the
+// three waves that share a SIMD carry equal MFMA work (the step time is the busiest SIMD's).  LDS images are
+// padded rows (row stride = channels * 2 + 16 bytes): a B fragment is `lane base + compile-time offset`.
+#pragma once
+#include "kernels_conv_bf.h"
+#include "kernels_conv_dx.h"   // rot16
+
+enum { TR_NC = 11, TR_NW = 12, TR_THREADS = TR_NW * 64 };
+enum {
+  TR_RSX = 80,                       // bytes per row of an x image ([36][32] bf16 + 16 pad)
+  TR_RSB = 272,                      // bytes per row of a 128-channel image
+  TR_PX = IMG_ROWS * TR_RSX,         // 2,880
+  TR_PB = IMG_ROWS * TR_RSB,         // 9,792
+  TR_O_X = 0,                        // [2 slots][x hi, x lo, pooled hi, pooled lo]
+  TR_O_A1 = TR_O_X + 2 * 4 * TR_PX,  // [2 bufs][ACT1 hi, lo, pooled hi, pooled lo]
+  TR_O_MID = TR_O_A1 + 2 * 4 * TR_PB,  // [2 bufs][MID hi, lo]
+  TR_O_SGN = TR_O_MID + 2 * 2 * TR_PB,  // [4 slots][10 layers][8 words]
+  TR_O_LUT = TR_O_SGN + 4 * 80 * 4,
+  TR_O_WL = TR_O_LUT + 4096,         // lo weight fragments of the one job too wide for the register file: [10 k-steps][64 lanes][16 B]
+  TR_LDS = TR_O_WL + 10 * 1024
+};
+
+// compile-time layer table of the trunk (layer ids of kInception in plan.hip)
+__host__ __device__ constexpr int tl_taps(int l) { return (l == 1 || l == 3 || l == 6) ? 3 : ((l == 2 || l == 8) ? 5 : 1); }
+__host__ __device__ constexpr int tl_g8(int l) { return l < 4 ? 4 : ((l == 6 || l == 8) ? 8 : 16); }   // 8-channel chunks per tap
+__host__ __device__ constexpr int tl_inch(int l) { return l == 8 ? 8 : 0; }                            // first chunk inside the input image
+__host__ __device__ constexpr int tl_pool(int l) { return (l == 3 || l == 9) ? 1 : 0; }
+__host__ __device__ constexpr int tl_cout(int l) { return l < 4 ? 27 : ((l == 5 || l == 7) ? 64 : (l == 9 ? 32 : 16)); }
+__host__ __device__ constexpr int tl_stage(int l) { return l < 4 ? 0 : ((l == 6 || l == 8) ? 2 : 1); }
+__host__ __device__ constexpr int tl_outk(int l) { return l < 4 ? 0 : ((l == 5 || l == 7) ? 1 : 2); }   // 0 ACT1, 1 MID, 2 ACT2
+__host__ __device__ constexpr int tl_ooff(int l) {
+  return l == 1 ? 32 : (l == 2 ? 64 : (l == 3 ? 96 : (l == 6 ? 16 : (l == 7 ? 64 : (l == 8 ? 32 : (l == 9 ? 48 : 0))))));
+}
+__host__ __device__ constexpr int tl_nks(int l) { return tl_taps(l) * tl_g8(l) / 4; }
+
+struct TrunkArgs {
+  const u16* xp[4];          // x hi, x lo, pooled x hi, pooled x lo: [B * L][32] bf16
+  WeightSlots ws;
+  const LayerDesc* layers;   // device table
+  const uint32_t* sign_in;   // packed Flipout signs, all layers (NoiseRefs layout)
+  const uint32_t* sign_out;
+  long examples;             // S * B of the call
+  u16* act1_hi;              // [S*B*L][128]  (training step only, else null)
+  u16* mid_hi;               // [S*B*L][128]
+  u16* act2_hi;              // [S*B*L][80]
+  u16* act2_lo;
+  unsigned char* amax;       // [S*B*L][128] arg-max codes of block 2's pooled branch (training step only)
+  int S, B, L, nsplit;
+};
+
+// WL_LDS: the job's lo weight fragments live in LDS (lane-linear, conflict-free) instead of registers
+template <int LAYER, int NT, bool WL_LDS = false>
+struct TJob {
+  static constexpr int layer = LAYER, nt = NT, nks = tl_nks(LAYER);
+  static constexpr bool wl_lds = WL_LDS;
+};
+struct TNone {
+  static constexpr int layer = -1, nt = 0, nks = 0;
+  static constexpr bool wl_lds = false;
+};
+
+typedef unsigned int tr_u32x4 __attribute__((ext_vector_type(4)));
+
+// register state + step body of one job
+template <int EM, class J>
+struct TrunkJobRun {
+  static constexpr int LY = J::layer, NT = J::nt, NKS = J::nks;
+  static constexpr bool FO = (EM == EM_FLIPOUT);
+  static constexpr int STAGE = tl_stage(LY), TAPS = tl_taps(LY), PAD = (TAPS - 1) / 2, G8 = tl_g8(LY);
+  static constexpr int RS = STAGE == 0 ? TR_RSX : TR_RSB;
+  static constexpr bool WLL = J::wl_lds;
+  bf16x8 wh[NKS], wl[WLL ? 1 : NKS], wb[FO ? NKS : 1];
+  f32x4 bias;
+  int nv;
+
+  __device__ __forceinline__ void init(const TrunkArgs& A, char* smem, int s, int lane) {
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const LayerDesc ly = A.layers[LY];
+    const long sa = A.ws.slot_stride_a * s, sb = A.ws.slot_stride_b * s;
+    const long row = (long)(NT * 16 + i16) * ly.KP + ly.w_off + g4 * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      wh[ks] = *(const bf16x8*)((const u16*)A.ws.a_hi + sa + row + ks * 32);
+      const bf16x8 l = *(const bf16x8*)((const u16*)A.ws.a_lo + sa + row + ks * 32);
+      if constexpr (WLL) *(bf16x8*)(smem + TR_O_WL + ks * 1024 + lane * 16) = l;
+      else wl[ks] = l;
+      if constexpr (FO) wb[ks] = *(const bf16x8*)((const u16*)A.ws.b + sb + row + ks * 32);
+    }
+    const int chb = NT * 16 + 4 * g4;
+    nv = tl_cout(LY) - chb;
+    const float* ba = A.ws.bias_a + (long)A.ws.bias_stride_a * s + ly.bias_off + chb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = r < nv ? ba[r] : 0.f;
+  }
+
+  // k = index of the window inside this workgroup's list, w = its index inside the particle
+  __device__ __forceinline__ void run(const TrunkArgs& A, char* smem, int k, int w, int s, int lane) const {
+    __builtin_amdgcn_sched_barrier(0);
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int par = k & 1;
+    const char* in_hi;
+    if constexpr (STAGE == 0) in_hi = smem + TR_O_X + par * 4 * TR_PX + (tl_pool(LY) ? 2 * TR_PX : 0);
+    else if constexpr (STAGE == 1) in_hi = smem + TR_O_A1 + par * 4 * TR_PB + (tl_pool(LY) ? 2 * TR_PB : 0);
+    else in_hi = smem + TR_O_MID + par * 2 * TR_PB;
+    constexpr int PLANE = STAGE == 0 ? TR_PX : TR_PB;
+    const char* lb = in_hi + i16 * RS + g4 * 16;
+    const uint32_t* sg = (const uint32_t*)(smem + TR_O_SGN) + (k & 3) * 80 + LY * 8;
+    const uint4* lut = (const uint4*)(smem + TR_O_LUT);
+    f32x4 acc_a[2], acc_b[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc_a[mt] = acc_b[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int tap = (ks * 4) / G8, c0 = (ks * 4) % G8;
+      bf16x8 wlk;
+      if constexpr (WLL) wlk = *(const bf16x8*)(smem + TR_O_WL + ks * 1024 + lane * 16);
+      else wlk = wl[ks];
+      tr_u32x4 fm = {0u, 0u, 0u, 0u};
+      if constexpr (FO) {
+        const int cl = c0 + g4;   // 8-channel chunk of the layer's own input channels
+        const uint32_t byte = (sg[cl >> 2] >> ((cl & 3) * 8)) & 0xffu;
+        fm = __builtin_bit_cast(tr_u32x4, lut[byte]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int off = (mt * 16 + tap - PAD + HALO) * RS + (tl_inch(LY) + c0) * 16;
+        const bf16x8 bh = *(const bf16x8*)(lb + off);
+        const bf16x8 bl = *(const bf16x8*)(lb + PLANE + off);
+        acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, acc_a[mt], 0, 0, 0);
+        acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, acc_a[mt], 0, 0, 0);
+        acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlk, bh, acc_a[mt], 0, 0, 0);
+        if constexpr (FO) {
+          const tr_u32x4 xb = __builtin_bit_cast(tr_u32x4, bh) ^ fm;
+          acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], __builtin_bit_cast(bf16x8, xb), acc_b[mt], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the next job's operand reads out of this job's epilogue (register pressure)
+    // ---------------- epilogue: bias, Flipout s_out, ReLU, hi/lo split ----------------
+    constexpr int chb0 = NT * 16;
+    const int chb = chb0 + 4 * g4;
+    uint32_t so = 0;
+    if constexpr (FO) so = (sg[4 + (chb0 >> 5)] >> (chb0 & 31)) >> (4 * g4);
+    f32x4 v[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = acc_a[mt][r];
+        if constexpr (FO) {
+          const float pb = acc_b[mt][r];
+          t = t + bias[r] + (((so >> r) & 1u) ? -pb : pb);
+        } else {
+          t += bias[r];
+        }
+        v[mt][r] = fmaxf(t, 0.f);   // every conv of the trunk is followed by ReLU (inception.py:48-60, 118-131)
+      }
+    }
+    const int L = A.L;
+    const long R0 = ((long)s * A.B + w) * L;
+    constexpr int OOFF = tl_ooff(LY), OUTK = tl_outk(LY);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = mt * 16 + i16;
+      uint2 hv, lv;
+      split4(v[mt], hv, lv);
+      if (row < L) {
+        if constexpr (OUTK == 0 || OUTK == 1) {
+          char* img = smem + (OUTK == 0 ? TR_O_A1 + par * 4 * TR_PB : TR_O_MID + par * 2 * TR_PB);
+          const int o = (row + HALO) * TR_RSB + (OOFF + chb) * 2;
+          *(uint2*)(img + o) = hv;
+          *(uint2*)(img + TR_PB + o) = lv;
+          u16* g = OUTK == 0 ? A.act1_hi : A.mid_hi;
+          if (g) *(uint2*)(g + (R0 + row) * 128 + OOFF + chb) = hv;
+        } else {
+          const long oo = (R0 + row) * 80 + OOFF + chb;
+          *(uint2*)(A.act2_hi + oo) = hv;
+          *(uint2*)(A.act2_lo + oo) = lv;
+        }
+      }
+    }
+    // ---------------- block 1 only: MaxPool1d(3,1,1) of the output rows (inception.py:99-104 reads it) ----------------
+    if constexpr (OUTK == 0) {
+      // rows live on the 16 lanes of a DPP row: row-1 / row+1 are one lane away; the seam between the two
+      // m-tiles (rows 15 | 16) takes the other accumulator.  torch keeps the FIRST maximum of (row-1, row, row+1).
+      f32x4 p[2];
+      uint32_t code[2] = {0u, 0u};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a0 = v[0][r], a1 = v[1][r];
+        const float up0 = rot16<0x121>(a0), up1 = rot16<0x121>(a1);   // lane i <- lane i-1 (mod 16)
+        const float dn0 = rot16<0x12F>(a0), dn1 = rot16<0x12F>(a1);   // lane i <- lane i+1 (mod 16)
+        {   // m-tile 0: row = i16
+          float best = a0;
+          uint32_t c = 1u;
+          if (i16 > 0 && up0 >= best) { best = up0; c = 0u; }
+          const float d = i16 == 15 ? dn1 : dn0;
+          if (i16 + 1 < L && d > best) { best = d; c = 2u; }
+          p[0][r] = best;
+          code[0] |= c << (8 * r);
+        }
+        {   // m-tile 1: row = 16 + i16
+          float best = a1;
+          uint32_t c = 1u;
+          const float u = i16 == 0 ? up0 : up1;
+          if (u >= best) { best = u; c = 0u; }
+          if (17 + i16 < L && dn1 > best) { best = dn1; c = 2u; }
+          p[1][r] = best;
+          code[1] |= c << (8 * r);
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 16 + i16;
+        uint2 hv, lv;
+        split4(p[mt], hv, lv);
+        if (row < L) {
+          char* img = smem + TR_O_A1 + par * 4 * TR_PB + 2 * TR_PB;
+          const int o = (row + HALO) * TR_RSB + (OOFF + chb) * 2;
+          *(uint2*)(img + o) = hv;
+          *(uint2*)(img + TR_PB + o) = lv;
+          if (A.amax) *(uint32_t*)(A.amax + (R0 + row) * 128 + OOFF + chb) = code[mt];
+        }
+      }
+    }
+  }
+};
+
+template <int EM>
+struct TrunkJobRun<EM, TNone> {
+  __device__ __forceinline__ void init(const TrunkArgs&, char*, int, int) {}
+  __device__ __forceinline__ void run(const TrunkArgs&, char*, int, int, int, int) const {}
+};
+
+template <class J>
+__device__ __forceinline__ constexpr int tj_stage() {
+  if constexpr (J::layer < 0) return 0;
+  else return tl_stage(J::layer);
+}
+
+template <int EM, class J0, class J1, class J2>
+__device__ __forceinline__ void trunk_role(const TrunkArgs& A, char* smem, int s, int split, int nwin, int lane) {
+  TrunkJobRun<EM, J0> r0;
+  TrunkJobRun<EM, J1> r1;
+  TrunkJobRun<EM, J2> r2;
+  r0.init(A, smem, s, lane);
+  r1.init(A, smem, s, lane);
+  r2.init(A, smem, s, lane);
+  __syncthreads();   // zero fill + sign table
+  lds_barrier();     // window 0 staged
+  const int nsteps = nwin + 2;
+  for (int t = 0; t < nsteps; ++t) {
+    {
+      const int k = t - tj_stage<J0>();
+      if (J0::layer >= 0 && k >= 0 && k < nwin) r0.run(A, smem, k, split + k * A.nsplit, s, lane);
+    }
+    {
+      const int k = t - tj_stage<J1>();
+      if (J1::layer >= 0 && k >= 0 && k < nwin) r1.run(A, smem, k, split + k * A.nsplit, s, lane);
+    }
+    {
+      const int k = t - tj_stage<J2>();
+      if (J2::layer >= 0 && k >= 0 && k < nwin) r2.run(A, smem, k, split + k * A.nsplit, s, lane);
+    }
+    lds_barrier();
+  }
+}
+
+// loader wave: x planes (and Flipout sign words) of the next windows, global -> registers -> LDS
+template <int EM>
+__device__ __forceinline__ void trunk_loader(const TrunkArgs& A, char* smem, int s, int split, int nwin, int lane) {
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  const int L = A.L;
+  const int nch = L * 4;                 // 16-byte chunks of one plane of one window
+  // chunk q of the 4 planes: q = j * 64 + lane over [4 planes][nch]
+  const int tot = 4 * nch;
+  // per-lane source offset / LDS destination of chunk q = j * 64 + lane (planes are `pstride` bytes apart in the
+  // workspace); only the last instruction (j = 7) can run past the end: its lanes load chunk 0 and do not store
+  const long pstride = (const char*)A.xp[1] - (const char*)A.xp[0];
+  const char* base = (const char*)A.xp[0] + ((long)split * L * 32) * 2;
+  long soff[8];
+  int dst[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int q = j * 64 + lane;
+    const int qq = q < tot ? q : 0;
+    const int pl = qq / nch, c = qq - pl * nch;
+    soff[j] = pl * pstride + (long)c * 16;
+    dst[j] = pl * TR_PX + ((c >> 2) + HALO) * TR_RSX + (c & 3) * 16;
+  }
+  const bool on7 = 7 * 64 + lane < tot;
+  const long wstep = (long)A.nsplit * L * 32 * 2;
+  // sign words: lane -> (layer = lane >> 3, word k = lane & 7) for layers 0..7; lanes 0..15 also layers 8, 9
+  const uint32_t* sg0 = nullptr;
+  const uint32_t* sg1 = nullptr;
+  long sst0 = 0, sst1 = 0;
+  if constexpr (FO) {
+    auto setup = [&](int layer, int kk, const uint32_t*& p, long& stride) {
+      const LayerDesc ly = A.layers[layer];
+      if (kk < 4 && kk < ly.sign_in_words) {
+        p = A.sign_in + ly.sign_in_off * A.examples + ((long)s * A.B + split) * ly.sign_in_words + kk;
+        stride = (long)A.nsplit * ly.sign_in_words;
+      } else if (kk >= 4 && kk - 4 < ly.sign_out_words && kk < 6) {
+        p = A.sign_out + ly.sign_out_off * A.examples + ((long)s * A.B + split) * ly.sign_out_words + (kk - 4);
+        stride = (long)A.nsplit * ly.sign_out_words;
+      }
+    };
+    setup(lane >> 3, lane & 7, sg0, sst0);
+    if (lane < 16) setup(8 + (lane >> 3), lane & 7, sg1, sst1);
+  }
+  uint4 b0, b1, b2, b3, b4, b5, b6, b7;
+  uint32_t sb0 = 0, sb1 = 0;
+#define TR_FETCH()                                              \
+  do {                                                          \
+    b0 = *(const uint4*)(base + soff[0]);                       \
+    b1 = *(const uint4*)(base + soff[1]);                       \
+    b2 = *(const uint4*)(base + soff[2]);                       \
+    b3 = *(const uint4*)(base + soff[3]);                       \
+    b4 = *(const uint4*)(base + soff[4]);                       \
+    b5 = *(const uint4*)(base + soff[5]);                       \
+    b6 = *(const uint4*)(base + soff[6]);                       \
+    b7 = *(const uint4*)(base + soff[7]);                       \
+    base += wstep;                                              \
+    if constexpr (FO) {                                         \
+      if (sg0) { sb0 = *sg0; sg0 += sst0; }                     \
+      if (sg1) { sb1 = *sg1; sg1 += sst1; }                     \
+    }                                                           \
+  } while (0)
+#define TR_PUT(K)                                                         \
+  do {                                                                    \
+    char* xs = smem + TR_O_X + ((K) & 1) * 4 * TR_PX;                     \
+    *(uint4*)(xs + dst[0]) = b0;                                          \
+    *(uint4*)(xs + dst[1]) = b1;                                          \
+    *(uint4*)(xs + dst[2]) = b2;                                          \
+    *(uint4*)(xs + dst[3]) = b3;                                          \
+    *(uint4*)(xs + dst[4]) = b4;                                          \
+    *(uint4*)(xs + dst[5]) = b5;                                          \
+    *(uint4*)(xs + dst[6]) = b6;                                          \
+    if (on7) *(uint4*)(xs + dst[7]) = b7;                                 \
+    if constexpr (FO) {                                                   \
+      uint32_t* sgw = (uint32_t*)(smem + TR_O_SGN) + ((K) & 3) * 80;      \
+      sgw[lane] = sb0;                                                    \
+      if (lane < 16) sgw[64 + lane] = sb1;                                \
+    }                                                                     \
+  } while (0)
+  if (nwin > 0) TR_FETCH();
+  __syncthreads();   // zero fill + sign table
+  if (nwin > 0) TR_PUT(0);
+  if (nwin > 1) TR_FETCH();
+  lds_barrier();     // window 0 staged
+  const int nsteps = nwin + 2;
+  for (int t = 0; t < nsteps; ++t) {
+    if (t + 1 < nwin) TR_PUT(t + 1);
+    if (t + 2 < nwin) TR_FETCH();
+    lds_barrier();
+  }
+#undef TR_FETCH
+#undef TR_PUT
+}
+
+template <int EM>
+__global__ __launch_bounds__(TR_THREADS) void trunk_fwd_kernel(const TrunkArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x / A.nsplit, split = blockIdx.x - s * A.nsplit;
+  const int nwin = (A.B - split + A.nsplit - 1) / A.nsplit;
+  {
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < TR_O_LUT / 4; k += TR_THREADS) z[k] = 0u;
+    build_sign_lut((uint4*)(smem + TR_O_LUT), tid, TR_THREADS);
+  }
+  // jobs: (layer, n-tile); waves w, w+4, w+8 share a SIMD -> k-step sums 23 | 23 | 22 | 16 (+ loader)
+  switch (wave) {
+    case 0: trunk_role<EM, TJob<8, 0, true>, TNone, TNone>(A, smem, s, split, nwin, lane); break;                    // 10
+    case 4: trunk_role<EM, TJob<7, 0>, TJob<7, 1>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
+    case 8: trunk_role<EM, TJob<2, 0>, TNone, TNone>(A, smem, s, split, nwin, lane); break;                    // 5
+    case 1: trunk_role<EM, TJob<6, 0>, TJob<0, 0>, TNone>(A, smem, s, split, nwin, lane); break;               // 6 + 1
+    case 5: trunk_role<EM, TJob<7, 2>, TJob<7, 3>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
+    case 9: trunk_role<EM, TJob<2, 1>, TJob<1, 0>, TNone>(A, smem, s, split, nwin, lane); break;               // 5 + 3
+    case 2: trunk_role<EM, TJob<5, 0>, TJob<5, 1>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
+    case 6: trunk_role<EM, TJob<4, 0>, TJob<3, 1>, TNone>(A, smem, s, split, nwin, lane); break;               // 4 + 3
+    case 10: trunk_role<EM, TJob<1, 1>, TJob<3, 0>, TJob<0, 1>>(A, smem, s, split, nwin, lane); break;         // 3 + 3 + 1
+    case 3: trunk_role<EM, TJob<5, 2>, TJob<5, 3>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
+    case 7: trunk_role<EM, TJob<9, 0>, TJob<9, 1>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
+    default: trunk_loader<EM>(A, smem, s, split, nwin, lane); break;
+  }
+}
+
+// bf16 hi/lo planes [rows][32] of the raw fp32 windows and of their MaxPool1d(3,1,1) copy (block 1's pooled
+// branch, inception.py:41-46); channel pads zero.  rows = B * L, pooling stays inside a window.
+__global__ void x_planes4_kernel(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * 32) return;
+  const long r = idx >> 5;
+  const int c = (int)(idx & 31);
+  float v = 0.f, p = 0.f;
+  if (c < F) {
+    v = x[r * F + c];
+    p = v;
+    const int l = (int)(r % L);
+    if (l > 0) p = fmaxf(p, x[(r - 1) * F + c]);
+    if (l + 1 < L) p = fmaxf(p, x[(r + 1) * F + c]);
+  }
+  const u16 h = f2bf(v), ph = f2bf(p);
+  hi[idx] = h;
+  lo[idx] = f2bf(v - bf2f(h));
+  phi[idx] = ph;
+  plo[idx] = f2bf(p - bf2f(ph));
+}

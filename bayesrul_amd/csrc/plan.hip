@@ -18,6 +18,7 @@
 #include "kernels_conv_bf.h"
 #include "kernels_conv_dx.h"
 #include "kernels_dense_fwd.h"
+#include "kernels_trunk.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -384,7 +385,7 @@ static void layout_workspace(BnnPlan* p) {
   p->o_preds = take((size_t)S * p->d.max_batch * 2 * 4);
   p->o_poolgrad = take((size_t)cap * p->d.win_length * 128 * 4);
   p->o_amax = take(p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION ? (size_t)cap * p->d.win_length * 128 : 0);
-  p->o_xplanes = take((size_t)2 * p->d.max_batch * p->d.win_length * 32 * 2);
+  p->o_xplanes = take((size_t)4 * p->d.max_batch * p->d.win_length * 32 * 2);   // x hi | lo | pooled hi | pooled lo
   p->o_tens = o;
   // activations / grads / q.  f32 plans keep fp32 rows; bf16x3 plans keep bf16 planes
   // (activation = hi + lo planes, gradient and q = one plane) except the net output z.
@@ -1256,16 +1257,64 @@ static int launch_dense_dx_bf(const GroupArgs& A0, int em, hipStream_t st, Prof*
   return 0;
 }
 
+// fused conv trunk (kernels_trunk.h): groups 0..2 of the Inception net in one launch
+static bool trunk_ok(const BnnPlan* p, const Ctx* c) {
+  return p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION && c->em != EM_LRT;
+}
+
+static int launch_trunk_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
+  const int L = p->d.win_length;
+  const long rows = (long)c->B * L;
+  const size_t plane = (size_t)p->d.max_batch * L * 32;
+  u16* xp = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
+  x_planes4_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xp, xp + plane, xp + 2 * plane,
+                                                                                      xp + 3 * plane, rows, L, p->d.n_features);
+  HIP_TRY(hipGetLastError());
+  GroupArgs G;
+  fill_group_args(p, a, c, 0, x, &G);
+  TrunkArgs T{};
+  for (int k = 0; k < 4; ++k) T.xp[k] = xp + k * plane;
+  T.ws = G.ws;
+  T.layers = G.layers;
+  T.sign_in = c->nz.sign_in;
+  T.sign_out = c->nz.sign_out;
+  T.examples = (long)c->S * c->B;
+  const TensorRef a1 = tens_ref(p, TI_ACT1, 0), md = tens_ref(p, TI_MID, 0), a2 = tens_ref(p, TI_ACT2, 0);
+  T.act1_hi = c->train ? (u16*)a1.p : nullptr;
+  T.mid_hi = c->train ? (u16*)md.p : nullptr;
+  T.act2_hi = (u16*)a2.p;
+  T.act2_lo = (u16*)a2.lo;
+  T.amax = c->train ? (unsigned char*)p->bufs.workspace + p->o_amax : nullptr;
+  T.S = c->S;
+  T.B = c->B;
+  T.L = L;
+  T.nsplit = std::max(1, std::min(c->B, 256 / std::max(1, c->S)));
+  const unsigned grid = (unsigned)(c->S * T.nsplit);
+  ProfScope ps_(&p->prof, PK_FWD, 0, c->st);
+  ps_.name("trunk_fwd_kernel<%d>", c->em);
+  if (c->em == EM_FLIPOUT) {
+    BNN_TRY(set_lds(trunk_fwd_kernel<EM_FLIPOUT>, TR_LDS));
+    trunk_fwd_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TR_THREADS), TR_LDS, c->st>>>(T);
+  } else {
+    BNN_TRY(set_lds(trunk_fwd_kernel<EM_PLAIN>, TR_LDS));
+    trunk_fwd_kernel<EM_PLAIN><<<dim3(grid), dim3(TR_THREADS), TR_LDS, c->st>>>(T);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
-  if (bf && p->d.net == BNN_NET_INCEPTION) {
+  const bool trunk = trunk_ok(p, c);
+  if (trunk) BNN_TRY(launch_trunk_fwd(p, a, c, x));
+  if (bf && p->d.net == BNN_NET_INCEPTION && !trunk) {
     const long rows = (long)c->B * p->d.win_length;
     u16* xh = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
     u16* xl = xh + (size_t)p->d.max_batch * p->d.win_length * 32;
     x_planes_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xh, xl, rows, p->d.n_features, 32);
     HIP_TRY(hipGetLastError());
   }
-  for (int gi = 0; gi < p->n_groups; ++gi) {
+  for (int gi = trunk ? 3 : 0; gi < p->n_groups; ++gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, x, &A);
     A.dbg = dbg_for(p, PK_FWD, gi);

@@ -68,6 +68,87 @@ def main():
         print("metrics ok")
     except Exception as e:  # pragma: no cover
         print("metrics fixtures skipped:", repr(e))
+    rmsce_and_frequentist(g)
+
+
+def rmsce_and_frequentist(g):
+    """rms_calibration_error (results/metrics.py:216-274) and the frequentist siblings HNN / NN
+    (models/frequentist.py:39-58,157-188): the reference's OWN code, run here on CPU.
+
+    Two environment shims, neither touching reference code:
+      * `Tensor.get_device()` is -1 for CPU tensors and the reference feeds it to `torch.linspace(device=...)`,
+        which raises.  For the duration of the run it returns torch.device("cpu").
+      * `pytorch_lightning` is absent: a stand-in module supplies `LightningModule` = nn.Module +
+        `save_hyperparameters` (collects the caller's ctor arguments) + `log` (records the value).  Only the
+        module's own step arithmetic is exercised; the Lightning loop is replaced by an explicit
+        zero_grad / backward / optimizer.step.
+    """
+    import functools
+    import inspect
+
+    class LightningModule(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.logged = {}
+
+        def save_hyperparameters(self, *a, logger=True, ignore=None):
+            loc = inspect.currentframe().f_back.f_locals
+            self.hparams = types.SimpleNamespace(
+                **{k: v for k, v in loc.items() if k not in ("self", "__class__") and k not in (ignore or [])})
+
+        def log(self, name, value, **kw):
+            self.logged[name] = float(value)
+
+    _stub("pytorch_lightning", LightningModule=LightningModule)
+    orig = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: self.device
+    try:
+        from bayesrul.models.frequentist import HNN, NN
+        from bayesrul.models.nets.inception import Inception
+        from bayesrul.results.metrics import rms_calibration_error
+
+        # ---- rmsce on three synthetic predictors (well calibrated, over-, under-confident)
+        n = 512
+        std = torch.rand(n, generator=g) + 0.5
+        yt = torch.rand(n, generator=g) * 100
+        yp = yt + torch.randn(n, generator=g) * std
+        out = {"std": std.numpy(), "yt": yt.numpy(), "yp": yp.numpy()}
+        for tag, f in (("cal", 1.0), ("over", 0.3), ("under", 3.0)):
+            out["rmsce_" + tag] = rms_calibration_error(yp, std * f, yt).numpy()
+        np.savez(os.path.join(HERE, "ref_rmsce.npz"), **out)
+        print("rmsce", {k: float(v) for k, v in out.items() if k.startswith("rmsce")})
+
+        # ---- HNN / NN: 3 optimiser steps at the shipped hyper-parameters (conf/experiment/ncmapss_hnn.yaml:17-23,
+        # conf/model/nn.yaml:6-10)
+        B = 16
+        x = torch.randn(B, 30, 18, generator=g)
+        y = torch.randint(0, 100, (B,), generator=g).float()
+        for tag, make in (("hnn", lambda net: HNN(net, functools.partial(torch.optim.Adam, lr=0.001574, weight_decay=1e-3),
+                                                   mc_samples=0, p_dropout=0)),
+                          ("nn", lambda net: NN(net, functools.partial(torch.optim.Adam, lr=0.001, weight_decay=1e-3)))):
+            torch.manual_seed(0)
+            model = make(Inception(30, 18))   # the ctor applies weights_init (frequentist.py:29, :169)
+            sd0 = {k: v.detach().clone().numpy() for k, v in model.net.state_dict().items()}
+            opt = model.configure_optimizers()
+            losses, logs = [], []
+            for i in range(3):
+                opt.zero_grad()
+                loss = model.training_step((x, y), i)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+                logs.append(dict(model.logged))
+            sd1 = {k: v.detach().clone().numpy() for k, v in model.net.state_dict().items()}
+            extra = {}
+            if tag == "hnn":
+                extra = {"mse": np.array([l["mse/train"] for l in logs]), "rmsce": np.array([l["rmsce/train"] for l in logs]),
+                         "sharp": np.array([l["sharp/train"] for l in logs])}
+            np.savez_compressed(os.path.join(HERE, f"ref_{tag}_steps.npz"), x=x.numpy(), y=y.numpy(),
+                                losses=np.array(losses), **extra, **{"sd0::" + k: v for k, v in sd0.items()},
+                                **{"sd1::" + k: v for k, v in sd1.items()})
+            print(tag, "losses", losses)
+    finally:
+        torch.Tensor.get_device = orig
 
 
 if __name__ == "__main__":
