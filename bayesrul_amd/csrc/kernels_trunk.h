@@ -29,8 +29,8 @@ enum {
   TR_O_A1 = TR_O_X + 2 * 4 * TR_PX,  // [2 bufs][ACT1 hi, lo, pooled hi, pooled lo]
   TR_O_MID = TR_O_A1 + 2 * 4 * TR_PB,  // [2 bufs][MID hi, lo]
   TR_O_SGN = TR_O_MID + 2 * 2 * TR_PB,  // [4 slots][10 layers][8 words]
-  TR_O_LUT = TR_O_SGN + 4 * 80 * 4,
-  TR_O_WL = TR_O_LUT + 4096,         // lo weight fragments of the one job too wide for the register file: [10 k-steps][64 lanes][16 B]
+  TR_O_LUT = TR_O_SGN + 4 * 80 * 4,     // 512 x 16 B: XOR mask of a dW fragment = s_in byte of its 8 K channels, s_out bit of its row
+  TR_O_WL = TR_O_LUT + 8192,         // lo weight fragments of the one job too wide for the register file: [10 k-steps][64 lanes][16 B]
   TR_LDS = TR_O_WL + 10 * 1024
 };
 
@@ -75,8 +75,19 @@ struct TNone {
 
 typedef unsigned int tr_u32x4 __attribute__((ext_vector_type(4)));
 
+// 512-entry table: index = s_out bit of the fragment's row << 8 | s_in byte of its 8 K channels -> XOR mask
+__device__ __forceinline__ void build_sign_lut2(uint4* lut, int tid, int nthreads) {
+  for (int e = tid; e < 512; e += nthreads) {
+    const uint32_t rs = (uint32_t)(e >> 8) & 1u;
+    uint32_t m[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m[q] = ((((e >> (2 * q)) & 1u) ^ rs) << 15) | ((((e >> (2 * q + 1)) & 1u) ^ rs) << 31);
+    lut[e] = make_uint4(m[0], m[1], m[2], m[3]);
+  }
+}
+
 // register state + step body of one job
-template <int EM, class J>
+template <int EM, bool TRAIN, class J>
 struct TrunkJobRun {
   static constexpr int LY = J::layer, NT = J::nt, NKS = J::nks;
   static constexpr bool FO = (EM == EM_FLIPOUT);
@@ -85,7 +96,6 @@ struct TrunkJobRun {
   static constexpr bool WLL = J::wl_lds;
   bf16x8 wh[NKS], wl[WLL ? 1 : NKS], wb[FO ? NKS : 1];
   f32x4 bias;
-  int nv;
 
   __device__ __forceinline__ void init(const TrunkArgs& A, char* smem, int s, int lane) {
     const int i16 = lane & 15, g4 = lane >> 4;
@@ -101,14 +111,14 @@ struct TrunkJobRun {
       if constexpr (FO) wb[ks] = *(const bf16x8*)((const u16*)A.ws.b + sb + row + ks * 32);
     }
     const int chb = NT * 16 + 4 * g4;
-    nv = tl_cout(LY) - chb;
+    const int nv = tl_cout(LY) - chb;
     const float* ba = A.ws.bias_a + (long)A.ws.bias_stride_a * s + ly.bias_off + chb;
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = r < nv ? ba[r] : 0.f;
   }
 
-  // k = index of the window inside this workgroup's list, w = its index inside the particle
-  __device__ __forceinline__ void run(const TrunkArgs& A, char* smem, int k, int w, int s, int lane) const {
+  // k = index of the window inside this workgroup's list; R0 = first row of the window in the [S*B*L] row space
+  __device__ __forceinline__ void run(const TrunkArgs& A, char* smem, int k, unsigned R0, int lane) const {
     __builtin_amdgcn_sched_barrier(0);
     const int i16 = lane & 15, g4 = lane >> 4;
     const int par = k & 1;
@@ -120,58 +130,45 @@ struct TrunkJobRun {
     const char* lb = in_hi + i16 * RS + g4 * 16;
     const uint32_t* sg = (const uint32_t*)(smem + TR_O_SGN) + (k & 3) * 80 + LY * 8;
     const uint4* lut = (const uint4*)(smem + TR_O_LUT);
-    f32x4 acc_a[2], acc_b[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc_a[mt] = acc_b[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int chb0 = NT * 16;
+    // one accumulator: out = bias + W_mu x  (+ Flipout: (s_out o dW o s_in) x, both signs folded into the dW fragment)
+    f32x4 acc[2];
+    acc[0] = acc[1] = bias;
+    uint32_t rs8 = 0;
+    if constexpr (FO) rs8 = ((sg[4 + (chb0 >> 5)] >> ((chb0 & 31) + i16)) & 1u) << 8;   // s_out of this lane's fragment row
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       const int tap = (ks * 4) / G8, c0 = (ks * 4) % G8;
       bf16x8 wlk;
       if constexpr (WLL) wlk = *(const bf16x8*)(smem + TR_O_WL + ks * 1024 + lane * 16);
       else wlk = wl[ks];
-      tr_u32x4 fm = {0u, 0u, 0u, 0u};
+      bf16x8 wbm = wh[ks];
       if constexpr (FO) {
         const int cl = c0 + g4;   // 8-channel chunk of the layer's own input channels
         const uint32_t byte = (sg[cl >> 2] >> ((cl & 3) * 8)) & 0xffu;
-        fm = __builtin_bit_cast(tr_u32x4, lut[byte]);
+        const tr_u32x4 fm = __builtin_bit_cast(tr_u32x4, lut[rs8 | byte]);
+        wbm = __builtin_bit_cast(bf16x8, __builtin_bit_cast(tr_u32x4, wb[ks]) ^ fm);
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int off = (mt * 16 + tap - PAD + HALO) * RS + (tl_inch(LY) + c0) * 16;
         const bf16x8 bh = *(const bf16x8*)(lb + off);
         const bf16x8 bl = *(const bf16x8*)(lb + PLANE + off);
-        acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, acc_a[mt], 0, 0, 0);
-        acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, acc_a[mt], 0, 0, 0);
-        acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlk, bh, acc_a[mt], 0, 0, 0);
-        if constexpr (FO) {
-          const tr_u32x4 xb = __builtin_bit_cast(tr_u32x4, bh) ^ fm;
-          acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], __builtin_bit_cast(bf16x8, xb), acc_b[mt], 0, 0, 0);
-        }
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlk, bh, acc[mt], 0, 0, 0);
+        if constexpr (FO) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbm, bh, acc[mt], 0, 0, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the next job's operand reads out of this job's epilogue (register pressure)
-    // ---------------- epilogue: bias, Flipout s_out, ReLU, hi/lo split ----------------
-    constexpr int chb0 = NT * 16;
+    // ---------------- epilogue: ReLU, hi/lo split ----------------
     const int chb = chb0 + 4 * g4;
-    uint32_t so = 0;
-    if constexpr (FO) so = (sg[4 + (chb0 >> 5)] >> (chb0 & 31)) >> (4 * g4);
     f32x4 v[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = acc_a[mt][r];
-        if constexpr (FO) {
-          const float pb = acc_b[mt][r];
-          t = t + bias[r] + (((so >> r) & 1u) ? -pb : pb);
-        } else {
-          t += bias[r];
-        }
-        v[mt][r] = fmaxf(t, 0.f);   // every conv of the trunk is followed by ReLU (inception.py:48-60, 118-131)
-      }
-    }
+      for (int r = 0; r < 4; ++r) v[mt][r] = fmaxf(acc[mt][r], 0.f);   // every conv of the trunk is followed by ReLU (inception.py:48-60, 118-131)
     const int L = A.L;
-    const long R0 = ((long)s * A.B + w) * L;
     constexpr int OOFF = tl_ooff(LY), OUTK = tl_outk(LY);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -184,12 +181,15 @@ struct TrunkJobRun {
           const int o = (row + HALO) * TR_RSB + (OOFF + chb) * 2;
           *(uint2*)(img + o) = hv;
           *(uint2*)(img + TR_PB + o) = lv;
-          u16* g = OUTK == 0 ? A.act1_hi : A.mid_hi;
-          if (g) *(uint2*)(g + (R0 + row) * 128 + OOFF + chb) = hv;
+          if constexpr (TRAIN) {
+            // 32-bit byte offsets from the (uniform) plane base: one scalar base + one vector offset per store
+            char* g = (char*)(OUTK == 0 ? A.act1_hi : A.mid_hi);
+            *(uint2*)(g + ((R0 + (unsigned)row) * 256u + (unsigned)((OOFF + chb) * 2))) = hv;
+          }
         } else {
-          const long oo = (R0 + row) * 80 + OOFF + chb;
-          *(uint2*)(A.act2_hi + oo) = hv;
-          *(uint2*)(A.act2_lo + oo) = lv;
+          const unsigned oo = (R0 + (unsigned)row) * 160u + (unsigned)((OOFF + chb) * 2);
+          *(uint2*)((char*)A.act2_hi + oo) = hv;
+          *(uint2*)((char*)A.act2_lo + oo) = lv;
         }
       }
     }
@@ -211,7 +211,7 @@ struct TrunkJobRun {
           const float d = i16 == 15 ? dn1 : dn0;
           if (i16 + 1 < L && d > best) { best = d; c = 2u; }
           p[0][r] = best;
-          code[0] |= c << (8 * r);
+          if constexpr (TRAIN) code[0] |= c << (8 * r);
         }
         {   // m-tile 1: row = 16 + i16
           float best = a1;
@@ -220,7 +220,7 @@ struct TrunkJobRun {
           if (u >= best) { best = u; c = 0u; }
           if (17 + i16 < L && dn1 > best) { best = dn1; c = 2u; }
           p[1][r] = best;
-          code[1] |= c << (8 * r);
+          if constexpr (TRAIN) code[1] |= c << (8 * r);
         }
       }
 #pragma unroll
@@ -233,17 +233,17 @@ struct TrunkJobRun {
           const int o = (row + HALO) * TR_RSB + (OOFF + chb) * 2;
           *(uint2*)(img + o) = hv;
           *(uint2*)(img + TR_PB + o) = lv;
-          if (A.amax) *(uint32_t*)(A.amax + (R0 + row) * 128 + OOFF + chb) = code[mt];
+          if constexpr (TRAIN) *(uint32_t*)(A.amax + ((R0 + (unsigned)row) * 128u + (unsigned)(OOFF + chb))) = code[mt];
         }
       }
     }
   }
 };
 
-template <int EM>
-struct TrunkJobRun<EM, TNone> {
+template <int EM, bool TRAIN>
+struct TrunkJobRun<EM, TRAIN, TNone> {
   __device__ __forceinline__ void init(const TrunkArgs&, char*, int, int) {}
-  __device__ __forceinline__ void run(const TrunkArgs&, char*, int, int, int, int) const {}
+  __device__ __forceinline__ void run(const TrunkArgs&, char*, int, unsigned, int) const {}
 };
 
 template <class J>
@@ -252,29 +252,31 @@ __device__ __forceinline__ constexpr int tj_stage() {
   else return tl_stage(J::layer);
 }
 
-template <int EM, class J0, class J1, class J2>
+template <int EM, bool TRAIN, class J0, class J1, class J2>
 __device__ __forceinline__ void trunk_role(const TrunkArgs& A, char* smem, int s, int split, int nwin, int lane) {
-  TrunkJobRun<EM, J0> r0;
-  TrunkJobRun<EM, J1> r1;
-  TrunkJobRun<EM, J2> r2;
+  TrunkJobRun<EM, TRAIN, J0> r0;
+  TrunkJobRun<EM, TRAIN, J1> r1;
+  TrunkJobRun<EM, TRAIN, J2> r2;
   r0.init(A, smem, s, lane);
   r1.init(A, smem, s, lane);
   r2.init(A, smem, s, lane);
   __syncthreads();   // zero fill + sign table
   lds_barrier();     // window 0 staged
   const int nsteps = nwin + 2;
+  // row indices fit 32 bits (the host refuses launches whose planes exceed 4 GiB)
+  const unsigned Rs = (unsigned)(((long)s * A.B + split) * A.L), Rstep = (unsigned)(A.nsplit * A.L);
   for (int t = 0; t < nsteps; ++t) {
     {
       const int k = t - tj_stage<J0>();
-      if (J0::layer >= 0 && k >= 0 && k < nwin) r0.run(A, smem, k, split + k * A.nsplit, s, lane);
+      if (J0::layer >= 0 && k >= 0 && k < nwin) r0.run(A, smem, k, Rs + k * Rstep, lane);
     }
     {
       const int k = t - tj_stage<J1>();
-      if (J1::layer >= 0 && k >= 0 && k < nwin) r1.run(A, smem, k, split + k * A.nsplit, s, lane);
+      if (J1::layer >= 0 && k >= 0 && k < nwin) r1.run(A, smem, k, Rs + k * Rstep, lane);
     }
     {
       const int k = t - tj_stage<J2>();
-      if (J2::layer >= 0 && k >= 0 && k < nwin) r2.run(A, smem, k, split + k * A.nsplit, s, lane);
+      if (J2::layer >= 0 && k >= 0 && k < nwin) r2.run(A, smem, k, Rs + k * Rstep, lane);
     }
     lds_barrier();
   }
@@ -372,7 +374,7 @@ __device__ __forceinline__ void trunk_loader(const TrunkArgs& A, char* smem, int
 #undef TR_PUT
 }
 
-template <int EM>
+template <int EM, bool TRAIN>
 __global__ __launch_bounds__(TR_THREADS) void trunk_fwd_kernel(const TrunkArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -382,23 +384,26 @@ __global__ __launch_bounds__(TR_THREADS) void trunk_fwd_kernel(const TrunkArgs A
   {
     uint32_t* z = (uint32_t*)smem;
     for (int k = tid; k < TR_O_LUT / 4; k += TR_THREADS) z[k] = 0u;
-    build_sign_lut((uint4*)(smem + TR_O_LUT), tid, TR_THREADS);
+    build_sign_lut2((uint4*)(smem + TR_O_LUT), tid, TR_THREADS);
   }
-  // jobs: (layer, n-tile); waves w, w+4, w+8 share a SIMD -> k-step sums 23 | 23 | 22 | 16 (+ loader)
+  // jobs: (layer, n-tile).  Dealt by cost (MFMAs + epilogue, the block-1 epilogue pools) so that every wave, and the
+  // three waves that share a SIMD (w, w+4, w+8), carry about the same work per step.
+#define TR_ROLE(...) trunk_role<EM, TRAIN, __VA_ARGS__>(A, smem, s, split, nwin, lane)
   switch (wave) {
-    case 0: trunk_role<EM, TJob<8, 0, true>, TNone, TNone>(A, smem, s, split, nwin, lane); break;                    // 10
-    case 4: trunk_role<EM, TJob<7, 0>, TJob<7, 1>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
-    case 8: trunk_role<EM, TJob<2, 0>, TNone, TNone>(A, smem, s, split, nwin, lane); break;                    // 5
-    case 1: trunk_role<EM, TJob<6, 0>, TJob<0, 0>, TNone>(A, smem, s, split, nwin, lane); break;               // 6 + 1
-    case 5: trunk_role<EM, TJob<7, 2>, TJob<7, 3>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
-    case 9: trunk_role<EM, TJob<2, 1>, TJob<1, 0>, TNone>(A, smem, s, split, nwin, lane); break;               // 5 + 3
-    case 2: trunk_role<EM, TJob<5, 0>, TJob<5, 1>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
-    case 6: trunk_role<EM, TJob<4, 0>, TJob<3, 1>, TNone>(A, smem, s, split, nwin, lane); break;               // 4 + 3
-    case 10: trunk_role<EM, TJob<1, 1>, TJob<3, 0>, TJob<0, 1>>(A, smem, s, split, nwin, lane); break;         // 3 + 3 + 1
-    case 3: trunk_role<EM, TJob<5, 2>, TJob<5, 3>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
-    case 7: trunk_role<EM, TJob<9, 0>, TJob<9, 1>, TNone>(A, smem, s, split, nwin, lane); break;               // 8
+    case 0: TR_ROLE(TJob<8, 0, true>, TNone, TNone); break;          // k5 64->16 (10 k-steps)
+    case 4: TR_ROLE(TJob<5, 0>, TJob<1, 0>, TNone); break;
+    case 8: TR_ROLE(TJob<5, 1>, TJob<5, 2>, TNone); break;
+    case 1: TR_ROLE(TJob<6, 0>, TJob<0, 0>, TNone); break;           // k3 64->16 (6 k-steps) + block-1 k1
+    case 5: TR_ROLE(TJob<5, 3>, TJob<1, 1>, TNone); break;
+    case 9: TR_ROLE(TJob<7, 0>, TJob<7, 1>, TNone); break;
+    case 2: TR_ROLE(TJob<2, 0>, TJob<4, 0>, TNone); break;           // block-1 k5 (5 k-steps) + a 1x1 tile
+    case 6: TR_ROLE(TJob<7, 2>, TJob<3, 0>, TNone); break;
+    case 10: TR_ROLE(TJob<7, 3>, TJob<0, 1>, TNone); break;
+    case 3: TR_ROLE(TJob<2, 1>, TJob<9, 0>, TNone); break;
+    case 7: TR_ROLE(TJob<9, 1>, TJob<3, 1>, TNone); break;
     default: trunk_loader<EM>(A, smem, s, split, nwin, lane); break;
   }
+#undef TR_ROLE
 }
 
 // bf16 hi/lo planes [rows][32] of the raw fp32 windows and of their MaxPool1d(3,1,1) copy (block 1's pooled

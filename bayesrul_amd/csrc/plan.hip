@@ -19,6 +19,8 @@
 #include "kernels_conv_dx.h"
 #include "kernels_dense_fwd.h"
 #include "kernels_trunk.h"
+#include "kernels_trunk_bwd.h"
+#include "kernels_trunk_dw.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -1289,15 +1291,83 @@ static int launch_trunk_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, cons
   T.B = c->B;
   T.L = L;
   T.nsplit = std::max(1, std::min(c->B, 256 / std::max(1, c->S)));
+  if ((long)c->S * c->B * L * 256 >= (1L << 32))
+    return fail(BNN_E_INVALID, "trunk kernels address rows with 32-bit byte offsets: S*B*L = %ld rows exceed 2^24", (long)c->S * c->B * L);
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_FWD, 0, c->st);
-  ps_.name("trunk_fwd_kernel<%d>", c->em);
+  ps_.name("trunk_fwd_kernel<%d, %s>", c->em, c->train ? "true" : "false");
+#define LAUNCH_TRUNK(EMV, TRV)                                                                  \
+  do {                                                                                          \
+    BNN_TRY(set_lds(trunk_fwd_kernel<EMV, TRV>, TR_LDS));                                       \
+    trunk_fwd_kernel<EMV, TRV><<<dim3(grid), dim3(TR_THREADS), TR_LDS, c->st>>>(T);             \
+  } while (0)
   if (c->em == EM_FLIPOUT) {
-    BNN_TRY(set_lds(trunk_fwd_kernel<EM_FLIPOUT>, TR_LDS));
-    trunk_fwd_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TR_THREADS), TR_LDS, c->st>>>(T);
+    if (c->train) LAUNCH_TRUNK(EM_FLIPOUT, true); else LAUNCH_TRUNK(EM_FLIPOUT, false);
   } else {
-    BNN_TRY(set_lds(trunk_fwd_kernel<EM_PLAIN>, TR_LDS));
-    trunk_fwd_kernel<EM_PLAIN><<<dim3(grid), dim3(TR_THREADS), TR_LDS, c->st>>>(T);
+    if (c->train) LAUNCH_TRUNK(EM_PLAIN, true); else LAUNCH_TRUNK(EM_PLAIN, false);
+  }
+#undef LAUNCH_TRUNK
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// dW of block 1 (kernels_trunk_dw.h): transposed-read tiles in registers across a particle's windows
+static int launch_trunk_dw1(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
+  GroupArgs G;
+  fill_group_args(p, a, c, 0, a->x, &G);
+  TrunkDw1Args T{};
+  const size_t plane = (size_t)p->d.max_batch * p->d.win_length * 32;
+  const u16* xp = (const u16*)((char*)p->bufs.workspace + p->o_xplanes);
+  T.x_hi = xp;
+  T.xp_hi = xp + 2 * plane;
+  T.g_act1 = (const u16*)tens_ref(p, TI_ACT1, 1).p;
+  T.layers = G.layers;
+  T.sign_in = c->nz.sign_in;
+  T.sign_out = c->nz.sign_out;
+  T.examples = (long)c->S * c->B;
+  T.gw_a = G.gw_a; T.gw_b = G.gw_b; T.gb_a = G.gb_a;
+  T.gw_stride = G.gw_stride; T.gb_stride = G.gb_stride;
+  T.S = c->S; T.B = c->B; T.L = p->d.win_length;
+  T.nsplit = std::max(1, std::min(c->B, 256 / std::max(1, c->S)));
+  const unsigned grid = (unsigned)(c->S * T.nsplit);
+  ProfScope ps_(&p->prof, PK_DW, 0, c->st);
+  ps_.name("trunk_dw1_kernel<%d>", c->em);
+  if (c->em == EM_FLIPOUT) trunk_dw1_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TW1_THREADS), TW1_LDS, c->st>>>(T);
+  else trunk_dw1_kernel<EM_PLAIN><<<dim3(grid), dim3(TW1_THREADS), TW1_LDS, c->st>>>(T);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// fused conv-trunk dX (kernels_trunk_bwd.h): dz of MID and of ACT1 from dY(ACT2), groups 2 and 1 in one launch
+static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
+  GroupArgs G;
+  fill_group_args(p, a, c, 1, a->x, &G);
+  TrunkDxArgs T{};
+  T.g_act2 = (const u16*)tens_ref(p, TI_ACT2, 1).p;
+  T.act2_hi = (const u16*)tens_ref(p, TI_ACT2, 0).p;
+  T.mid_hi = (const u16*)tens_ref(p, TI_MID, 0).p;
+  T.act1_hi = (const u16*)tens_ref(p, TI_ACT1, 0).p;
+  T.amax = (const unsigned char*)p->bufs.workspace + p->o_amax;
+  T.g_mid = (u16*)tens_ref(p, TI_MID, 1).p;
+  T.g_act1 = (u16*)tens_ref(p, TI_ACT1, 1).p;
+  T.ws = G.ws;
+  T.layers = G.layers;
+  T.sign_in = c->nz.sign_in;
+  T.sign_out = c->nz.sign_out;
+  T.examples = (long)c->S * c->B;
+  T.S = c->S;
+  T.B = c->B;
+  T.L = p->d.win_length;
+  T.nsplit = std::max(1, std::min(c->B, 256 / std::max(1, c->S)));
+  const unsigned grid = (unsigned)(c->S * T.nsplit);
+  ProfScope ps_(&p->prof, PK_DX, 1, c->st);
+  ps_.name("trunk_dx_kernel<%d>", c->em);
+  if (c->em == EM_FLIPOUT) {
+    BNN_TRY(set_lds(trunk_dx_kernel<EM_FLIPOUT>, TX_LDS));
+    trunk_dx_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TX_THREADS), TX_LDS, c->st>>>(T);
+  } else {
+    BNN_TRY(set_lds(trunk_dx_kernel<EM_PLAIN>, TX_LDS));
+    trunk_dx_kernel<EM_PLAIN><<<dim3(grid), dim3(TX_THREADS), TX_LDS, c->st>>>(T);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1365,6 +1435,8 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     A.dbg = dbg_for(p, PK_DW, gi);
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
+    else if (!A.g.is_dense && gi == 0 && trunk_ok(p, c))
+      BNN_TRY(launch_trunk_dw1(p, a, c));
     else if (!A.g.is_dense)
       BNN_TRY(launch_conv_dw_mw(A, p->layers, c->em, c->st, &p->prof, gi));
     else if (A.g.n_branch == 1 && !A.g.in_bcast && A.g.br[0].cout <= 64 && (A.g.br[0].cout % 8) == 0 &&
@@ -1379,6 +1451,11 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       (A.g.br[b].pool ? any_pool : any_direct) = true;
     }
     const bool conv_bf = p->d.prec == BNN_PREC_BF16X3 && !A.g.is_dense;
+    if (conv_bf && trunk_ok(p, c)) {
+      // groups 2 and 1: one fused launch once dY(ACT2) is complete (the dense layer's dX ran before group 2)
+      if (gi == 2) BNN_TRY(launch_trunk_dx(p, a, c));
+      continue;
+    }
     if (conv_bf && (any_direct || any_pool)) {
       // one launch: direct and pooled branches, arg-max scatter included
       A.dbg = dbg_for(p, PK_DX, gi);

@@ -1,18 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — ELBO-step MC-samples x windows / sec of the MI355X SVI/ELBO path.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run,
-one rank per GPU, RCCL).  A step = one full svi.step over one batch of synthetic
-N-CMAPSS-shaped windows: sample -> forward -> NLL -> backward -> [all-reduce] -> ClippedAdam.
-Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  A step = one full svi.step over one batch of
+synthetic N-CMAPSS-shaped windows resident in HBM: sample -> forward -> NLL -> backward -> [all-reduce] ->
+ClippedAdam.  N > 1: one rank per GPU over RCCL, either under an outer `python -m torch.distributed.run ...`
+(RANK / WORLD_SIZE set) or launched plainly — then this script starts that launcher itself, BEFORE any GPU call,
+and exits with its code.  Rank 0 prints ONE JSON line.
+
+Besides the contract's fields the line carries
+  roofline      dominant kernel symbol: algorithmic FLOPs per launch / its mean launch duration
+                (HIP events recorded inside the library on the launch stream during the timed region) vs the dense MFMA peak
+  hbm           algorithmic bytes per step next to the measured PMC traffic of the committed
+                rocprofv3 passes (profiles/): a traffic ratio, not a roofline fraction
+  median        median per-step time over >= 200 separately timed steps (events between steps)
+  fp32_plan     the same workload on the exact-fp32 MFMA plan (the reference's arithmetic precision)
+  b100          the same workload at the reference's batch of 100 windows (launch-bound regime)
+  cpu_baseline  the CPU restatement (oracle/, kind "port") on this box's host cores: all cores at the workload's own
+                batch, one thread on a smaller sample
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -38,33 +50,31 @@ WORKLOADS = {
 }
 N_DATA = 238200
 
-# algorithmic MACs per sample-window of each branch group (SURVEY.md §8(d)); 1 MAC = 2 FLOP
+# algorithmic MACs per sample-window of each branch group (SURVEY.md 8(d)); 1 MAC = 2 FLOP
 GROUP_MACS = {
     "inception": [30 * 27 * (18 + 54 + 90 + 54), 30 * 108 * (16 + 64 + 64 + 32), 30 * (192 * 16 + 320 * 16),
                   2400 * 64, 64 * 2],
     "linear": [540 * 256, 256 * 128, 128 * 128, 128 * 32, 32 * 2],
 }
-# algorithmic HBM bytes per MC-sample x window of each (kernel kind, branch group), Inception with
-# bf16-plane storage (activation = hi + lo planes = 4 B/elem forward, hi only = 2 B/elem backward;
-# gradients 2 B/elem): read + written, LRT adds a q plane
-def group_bytes(net, kind, grp, em, S):
-    if net != "inception":
-        return None
-    L = 30
-    q = 2 if em == 1 else 0  # bytes/elem of the LRT q plane
-    fwd = [L * 32 * 4 / S + L * 128 * (4 + q), L * 128 * 4 + L * 176 * (4 + q), L * 128 * 4 + L * 32 * (4 + q),
-           L * 80 * 4 + 64 * (4 + q), 64 * 4 + 2 * 4]
-    dx = [0, L * 176 * (4 + q) + 2 * L * 128 * 2, L * 32 * (4 + q) + L * 128 * 2, 64 * (4 + q) + L * 80 * 2, 2 * 8 + 64 * 2]
-    dw = [L * 32 * 2 / S + L * 128 * (4 + q), L * 128 * 2 + L * 176 * (4 + q), L * 128 * 2 + L * 32 * (4 + q),
-          L * 80 * 2 + 64 * (4 + q), 64 * 2 + 2 * 8]
-    return {"fwd": fwd, "dx": dx, "dw": dw}[kind][grp]
-
-
-PMC_SUMMARY = "r01_final_flipout_conv_s10_pmc_summary.csv"
+N_PARAMS = {"inception": 187142, "linear": 192098}
+# branch groups one launch of a fused kernel covers (the library reports the symbol per (kind, group) tag)
+FUSED_GROUPS = {"trunk_fwd_kernel": (0, 1, 2), "trunk_dx_kernel": (1, 2), "trunk_dw_kernel": (0, 1, 2)}
 PEAK_TFLOPS = {"bf16x3": 2500.0, "f32": 157.3}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def algorithmic_bytes_per_step(net, S, B, predict):
+    """windows 2,164 B each (read once per step), (mu, rho) read + written, Adam m / v read + written,
+    gradient written + read = 8 * 2P * 4 B; weight noise is not algorithmic (in-kernel Philox); activations are assumed
+    on chip."""
+    P = N_PARAMS[net]
+    if predict:
+        return B * 2160 + 2 * P * 4 + 4 * B * 4
+    return B * 2164 + 8 * 2 * P * 4
 
 
 def synth(B_total, seed=1234):
+    import torch
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B_total, 30, 18, generator=g)
     y = torch.randint(0, 100, (B_total,), generator=g).float()
@@ -75,6 +85,8 @@ def mu0_for(net):
     """Seeded init with the reference's initialisers (utils/miscellaneous.py:53-63): xavier-normal
     conv / kaiming-normal linear weights, torch-default biases."""
     import math
+
+    import torch
     from bayesrul_amd.models.nets.spec import net_layers
     g = torch.Generator().manual_seed(0)
     out = {}
@@ -91,35 +103,72 @@ def mu0_for(net):
     return out
 
 
-def cpu_baseline(wl, seconds_target=15.0):
-    """CPU restatement of the reference path (oracle/, kind 'port') timed on this box's host
-    cores: fp32, sequential particle loop, per-layer F.conv1d / F.linear, autograd, ClippedAdam."""
-    from oracle import restatement as R
-    # the 1-GPU box grants a 16-core CPU share; more threads than that only oversubscribes
+def _cpu_model():
     try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))
-    torch.set_num_threads(cores)
-    B, S = 100, wl["S"]
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_time(wl, B, threads, seconds_target, max_steps):
+    import torch
+    from oracle import restatement as R
+    torch.set_num_threads(threads)
+    S = wl["S"]
     cfg = R.ElboConfig(net=wl["net"], guide=wl["guide"], fit_context=wl["fit_context"], dataset_size=N_DATA,
                        prior_scale=wl["prior_scale"])
     st = R.SviState(cfg, R.init_mu0(wl["net"], 0, torch.float32), wl["q_scale"], R.AdamConfig(lr=wl["lr"]),
                     dtype=torch.float32)
     x, y = synth(B)
-    gen = torch.Generator().manual_seed(4321)
-    noise = R.make_noise(cfg, B, S, gen, dtype=torch.float32)
+    noise = R.make_noise(cfg, B, S, torch.Generator().manual_seed(4321), dtype=torch.float32)
     st.step(x, y, noise)  # warm-up
-    n, t0 = 0, time.time()
-    while True:
+    ts = []
+    t_all = time.time()
+    while len(ts) < max_steps and (time.time() - t_all < seconds_target or len(ts) < 2):
+        t0 = time.time()
         st.step(x, y, noise)
-        n += 1
-        if time.time() - t0 > seconds_target or n >= 100:
-            break
-    dt = (time.time() - t0) / n
-    return {"value": S * B / dt, "unit": "MC-samples*windows/s", "cores": cores, "kind": "port",
-            "sample": f"{n} steps of B={B}, S={S}, fp32 torch CPU restatement ({dt * 1e3:.1f} ms/step)"}
+        ts.append(time.time() - t0)
+    dt = statistics.median(ts)
+    return S * B / dt, dt, len(ts)
+
+
+def cpu_baseline(wl):
+    """CPU restatement of the reference path (oracle/, kind 'port') timed on this box's host cores: fp32, sequential
+    particle loop, per-layer F.conv1d / F.linear, autograd, ClippedAdam — the structure of the reference's Pyro/TyXe
+    step.  A reported baseline, not the optimisation target."""
+    import torch
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))   # the 1-GPU box grants a 16-core share; more threads only oversubscribe
+    B = wl["B"]
+    v_all, dt_all, n_all = _cpu_time(wl, B, cores, 14.0, 50)
+    b1 = min(B, 100)
+    v_one, dt_one, n_one = _cpu_time(wl, b1, 1, 8.0, 20)
+    torch.set_num_threads(cores)
+    return {"value": v_all, "unit": "MC-samples*windows/s", "cores": cores, "kind": "port",
+            "sample": f"median of {n_all} steps of B={B}, S={wl['S']}, fp32 torch CPU restatement, {cores} threads "
+                      f"({dt_all * 1e3:.0f} ms/step)",
+            "one_thread": {"value": v_one, "sample": f"median of {n_one} steps of B={b1}, S={wl['S']} ({dt_one * 1e3:.0f} ms/step)"},
+            "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "torch": torch.__version__}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` launched plainly: start one rank per GPU through torch's launcher before any GPU
+    call of this process and hand its exit code on."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -131,18 +180,21 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: workload's)")
     ap.add_argument("--prec", default="bf16x3", choices=["bf16x3", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-companions", action="store_true", help="skip the fp32_plan / b100 / median companions")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+
+    import torch
+    import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -154,44 +206,70 @@ def main():
         wl["B"] = args.batch
     S, B = wl["S"], wl["B"]
     predict = bool(wl.get("predict"))
-    eng = SviEngine(net=wl["net"], guide=wl["guide"], fit_context=wl["fit_context"], prec=args.prec, max_particles=S,
-                    max_batch=B, device=dev, max_windows=wl.get("chunk_particles", 0) * B)
-    eng.init_params(mu0_for(wl["net"]), wl["q_scale"])
-    xg, yg = synth(B * world)
-    x = xg[rank * B:(rank + 1) * B].contiguous().to(dev)
-    y = yg[rank * B:(rank + 1) * B].contiguous().to(dev)
     hyp = AdamHyper(lr=wl["lr"], betas=(0.95, 0.999), clip_norm=15.0)
+    xg, yg = synth(max(B, 100) * world)
 
-    def one_step():
-        if predict:   # windows shard, no collective
-            return eng.predict(x, S, seed=4321, want_samples=False)[0]
-        if world > 1:
-            return dp_step(eng, x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, rank, world, seed=4321)
-        return eng.step(x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, seed=4321)
+    def make(prec, batch):
+        eng = SviEngine(net=wl["net"], guide=wl["guide"], fit_context=wl["fit_context"], prec=prec, max_particles=S,
+                        max_batch=batch, device=dev, max_windows=wl.get("chunk_particles", 0) * batch)
+        eng.init_params(mu0_for(wl["net"]), wl["q_scale"])
+        x = xg[rank * batch:(rank + 1) * batch].contiguous().to(dev)
+        y = yg[rank * batch:(rank + 1) * batch].contiguous().to(dev)
 
+        def one_step():
+            if predict:   # windows shard, no collective
+                return eng.predict(x, S, seed=4321, want_samples=False)[0]
+            if world > 1:
+                return dp_step(eng, x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, rank, world, seed=4321)
+            return eng.step(x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, seed=4321)
+        return eng, one_step
+
+    eng, one_step = make(args.prec, B)
     ncontr = 2 if (wl["fit_context"] in ("lrt", "flipout") and not predict) else 1
-    em = 0 if predict else {"lrt": 1, "flipout": 2}.get(wl["fit_context"], 0)
     macs = GROUP_MACS[wl["net"]]
 
     def by_symbol(prof, nsteps):
-        """{symbol: [ms, launches, algorithmic flops, algorithmic bytes, tags]} of the group kernels.
-        One symbol may serve several branch groups; its algorithmic FLOPs per launch = (sum over its
+        """{symbol: [ms, launches, algorithmic flops, tags]} of the contraction kernels.  One symbol may serve several
+        branch groups (and a fused kernel covers several per launch); its algorithmic FLOPs per launch = (sum over its
         launches of 2*MAC*contractions*S*B) / launches, so achieved = total FLOPs / total time."""
         agg, seen = {}, set()
         for (kind, grp), (tot_ms, cnt) in prof.items():
             if kind not in ("fwd", "dx", "dw", "pool_bwd"):
                 continue
             sym = eng.profile_symbol(kind, grp) or f"{kind}[{grp}]"
-            a = agg.setdefault(sym, [0.0, 0, 0.0, 0.0, []])
+            a = agg.setdefault(sym, [0.0, 0, 0.0, []])
             a[0] += tot_ms
             a[1] += cnt
-            a[4].append((kind, grp))
+            a[3].append((kind, grp))
             if kind == "pool_bwd" or (kind, grp) in seen:
                 continue
             seen.add((kind, grp))
-            a[2] += 2.0 * macs[grp] * ncontr * S * B * nsteps
-            a[3] += (group_bytes(wl["net"], kind, grp, em, S) or 0.0) * S * B * nsteps
+            groups = FUSED_GROUPS.get(sym.split("<")[0], (grp,))
+            if kind == "dx":   # block 1 needs no dX (its input is the data)
+                groups = [g for g in groups if g > 0]
+            a[2] += sum(2.0 * macs[g] * ncontr * S * B * nsteps for g in groups)
         return agg
+
+    def timed_region(step_fn, engine, nsteps, only):
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        if only is not None:
+            engine.profile(True, only=only)
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            res = step_fn()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, res
 
     # warm-up; its last steps run with every launch recorded to find the dominant kernel symbol
     npre = min(3, args.warmup)
@@ -203,29 +281,13 @@ def main():
     torch.cuda.synchronize(dev)
     pre = by_symbol(eng.profile_read(), max(1, npre)) if npre else {}
     eng.profile(False)
-    dom_tags = max(pre.items(), key=lambda kv: kv[1][0])[1][4] if pre else None
+    dom_tags = max(pre.items(), key=lambda kv: kv[1][0])[1][3] if pre else None
 
-    # timed region: K steps; HIP events (on the launch stream, inside the library) bracket only the
-    # launches of the dominant symbol -- events around every kernel cost ~10 us per launch
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    eng.profile(True, only=dom_tags)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = one_step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
+    # timed region: EXACTLY K steps; HIP events (on the launch stream, inside the library) bracket only the launches
+    # of the dominant symbol -- events around every kernel cost ~5 us per launch
+    dt, res = timed_region(one_step, eng, args.steps, dom_tags)
     prof = eng.profile_read()
     eng.profile(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     loss = float(res[0].flatten()[0]) if predict else float(res[0])   # predict: first aggregated prediction
 
     # separate untimed pass: every launch recorded -> per-kernel table of the report
@@ -236,28 +298,69 @@ def main():
     torch.cuda.synchronize(dev)
     post = eng.profile_read()
     eng.profile(False)
+    agg = by_symbol(prof, args.steps)
+    kernel_symbols = {f"{k[0]}[{k[1]}]": eng.profile_symbol(*k) for k in sorted(post)}
+
+    def median_ms(step_fn, n):
+        """median per-step time: events between the steps on the launch stream, one synchronisation at the end"""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record()
+        for i in range(n):
+            step_fn()
+            evs[i + 1].record()
+        torch.cuda.synchronize(dev)
+        return statistics.median(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+
+    companions = {}
+    if not args.no_companions and world == 1:
+        nmed = 200 if not predict else 20
+        companions["median"] = {"timed_steps": nmed, "ms_per_step": median_ms(one_step, nmed)}
+        companions["median"]["value"] = S * B / (companions["median"]["ms_per_step"] * 1e-3)
+        if not predict:
+            # the reference's arithmetic is fp32: the same workload on the exact-fp32 MFMA plan
+            if args.prec != "f32":
+                eng32, step32 = make("f32", B)
+                for _ in range(2):
+                    step32()
+                m = median_ms(step32, 10)
+                companions["fp32_plan"] = {"timed_steps": 10, "ms_per_step": m, "value": S * B / (m * 1e-3),
+                                           "dtype": "f32 (v_mfma_f32_16x16x4_f32)"}
+                del eng32
+                torch.cuda.empty_cache()
+            # the reference's batch size (conf/datamodule/ncmapss.yaml: batch_size 100): launch-bound regime
+            if B != 100:
+                eng100, step100 = make(args.prec, 100)
+                for _ in range(5):
+                    step100()
+                m = median_ms(step100, 200)
+                companions["b100"] = {"timed_steps": 200, "windows_per_gpu": 100, "ms_per_step": m,
+                                      "value": S * 100 / (m * 1e-3)}
+                del eng100
+                torch.cuda.empty_cache()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = S * B * world / (dt / args.steps)
-        agg = by_symbol(prof, args.steps)
-        sym, (tot_ms, cnt, flops_tot, bytes_tot, _) = max(agg.items(), key=lambda kv: kv[1][0])
+        sym, (tot_ms, cnt, flops_tot, _) = max(agg.items(), key=lambda kv: kv[1][0])
         flops_launch = flops_tot / cnt
         avg_s = tot_ms / cnt * 1e-3
         achieved = flops_launch / avg_s / 1e12
         peak = PEAK_TFLOPS[args.prec]
-        # HBM bytes per launch of that symbol from the committed PMC passes (profiles/, same workload):
-        # (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 read correction of MI355X_MICROARCH.md applied
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", PMC_SUMMARY)
-        if args.workload == "flipout_conv_s10" and args.prec == "bf16x3" and not args.batch and os.path.exists(pmc):
+        # HBM bytes from the committed PMC passes (profiles/, same workload): (2*FETCH_SIZE + WRITE_SIZE) KB per
+        # launch, the gfx950 read correction of MI355X_MICROARCH.md applied
+        traffic, step_traffic = None, None
+        pmc = os.path.join(ROOT, "profiles", f"r02_{args.workload}_pmc_summary.csv")
+        if args.prec == "bf16x3" and not args.batch and os.path.exists(pmc):
             import csv
+            step_traffic = 0.0
             for r in csv.DictReader(open(pmc)):
+                b = (2 * float(r["FETCH_SIZE_KB_per_launch"]) + float(r["WRITE_SIZE_KB_per_launch"])) * 1024
+                step_traffic += b * float(r.get("launches_per_step", 1) or 1)
                 if sym in r["kernel"]:
-                    traffic = (2 * float(r["FETCH_SIZE_KB_per_launch"]) + float(r["WRITE_SIZE_KB_per_launch"])) * 1024
-                    break
-        bytes_launch = bytes_tot / cnt
+                    traffic = b
+        alg_bytes = algorithmic_bytes_per_step(wl["net"], S, B, predict)
         kernels = {f"{k[0]}[{k[1]}]": round(v[0] / npost, 4) for k, v in sorted(post.items())}
+        total_flops = sum(2.0 * m for m in macs) * (1 if predict else 3) * ncontr * S * B
         out = {
             "metric": ("predictive-pass MC-samples x windows/sec, Conv BNN on N-CMAPSS" if predict else
                        "ELBO-step MC-samples x windows/sec, Conv BNN on N-CMAPSS"),
@@ -267,17 +370,23 @@ def main():
             "config": {"workload": args.workload, "net": wl["net"],
                        "estimator": "plain-normal predictive" if predict else (wl["fit_context"] or wl["guide"]),
                        "mc_samples": S, "windows_per_gpu": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}", "loss": loss},
+                       "parallelism": f"dp{world}", "loss": loss,
+                       "arithmetic": ("forward mean path split-bf16 (hi+lo, 3 MFMAs, fp32 accumulate); second "
+                                      "contraction and backward contractions single bf16" if args.prec == "bf16x3"
+                                      else "exact fp32 MFMA")},
             "roofline": {"bound": "mfma", "kernel": sym, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_us": avg_s * 1e6, "flops_per_launch": flops_launch,
-                         "launches_per_step": cnt / args.steps},
-            "roofline_hbm": {"bound": "hbm", "kernel": sym, "achieved": bytes_launch / avg_s / 1e9, "peak": 8000.0,
-                             "unit": "GB/s", "frac": bytes_launch / avg_s / 1e9 / 8000.0,
-                             "algorithmic_bytes_per_launch": bytes_launch, "traffic": traffic},
+                         "launches_per_step": cnt / args.steps,
+                         "whole_step": {"algorithmic_flops": total_flops, "achieved": total_flops / (ms * 1e-3) / 1e12,
+                                        "frac": total_flops / (ms * 1e-3) / 1e12 / peak}},
+            "hbm": {"algorithmic_bytes_per_step": alg_bytes, "measured_bytes_per_step": step_traffic,
+                    "traffic_ratio": (step_traffic / alg_bytes) if step_traffic else None,
+                    "algorithmic_GBps": alg_bytes / (ms * 1e-3) / 1e9, "peak_GBps": HBM_PEAK_GBS},
             "kernel_ms_per_step": kernels,   # separate pass with events around every launch
-            "kernel_symbols": {f"{k[0]}[{k[1]}]": eng.profile_symbol(*k) for k in sorted(post)},
+            "kernel_symbols": kernel_symbols,
         }
+        out.update(companions)
         if world == 1 and not args.no_cpu_baseline and not predict:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out))

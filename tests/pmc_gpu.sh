@@ -14,6 +14,6 @@ for d in ('pmc_sq','pmc_sq2'):
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[(k, r['Counter_Name'])] += 1
     for k, v in acc.items():
-        if 'conv_' in k or 'dense_' in k or 'pool' in k:
+        if 'conv_' in k or 'dense_' in k or 'pool' in k or 'trunk' in k:
             print(k, {c: round(x / cnt[(k, c)]) for c, x in v.items()})
 PY
