@@ -16,6 +16,11 @@
 // three waves that share a SIMD carry equal MFMA work (the step time is the busiest SIMD's).  LDS images are
 // padded rows (row stride = channels * 2 + 16 bytes): a B fragment is `lane base + compile-time offset`.
 #pragma once
+// diagnostics builds only (tests/probes/ablate_gpu.sh): timing with parts of the kernel removed; results are wrong.
+// The product library is built with TR_ABL == 0.
+#ifndef TR_ABL
+#define TR_ABL 0
+#endif
 #include "kernels_conv_bf.h"
 #include "kernels_conv_dx.h"   // rot16
 
@@ -137,7 +142,7 @@ struct TrunkJobRun {
     uint32_t rs8 = 0;
     if constexpr (FO) rs8 = ((sg[4 + (chb0 >> 5)] >> ((chb0 & 31) + i16)) & 1u) << 8;   // s_out of this lane's fragment row
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+    for (int ks = 0; ks < ((TR_ABL & 2) ? 0 : NKS); ++ks) {
       const int tap = (ks * 4) / G8, c0 = (ks * 4) % G8;
       bf16x8 wlk;
       if constexpr (WLL) wlk = *(const bf16x8*)(smem + TR_O_WL + ks * 1024 + lane * 16);
@@ -181,20 +186,24 @@ struct TrunkJobRun {
           const int o = (row + HALO) * TR_RSB + (OOFF + chb) * 2;
           *(uint2*)(img + o) = hv;
           *(uint2*)(img + TR_PB + o) = lv;
-          if constexpr (TRAIN) {
+          if constexpr (TRAIN && !(TR_ABL & 1)) {
             // 32-bit byte offsets from the (uniform) plane base: one scalar base + one vector offset per store
             char* g = (char*)(OUTK == 0 ? A.act1_hi : A.mid_hi);
             *(uint2*)(g + ((R0 + (unsigned)row) * 256u + (unsigned)((OOFF + chb) * 2))) = hv;
           }
         } else {
           const unsigned oo = (R0 + (unsigned)row) * 160u + (unsigned)((OOFF + chb) * 2);
-          *(uint2*)((char*)A.act2_hi + oo) = hv;
-          *(uint2*)((char*)A.act2_lo + oo) = lv;
+          if constexpr (!(TR_ABL & 1)) {
+            *(uint2*)((char*)A.act2_hi + oo) = hv;
+            *(uint2*)((char*)A.act2_lo + oo) = lv;
+          } else {
+            asm volatile("" ::"v"(hv.x), "v"(hv.y), "v"(lv.x), "v"(lv.y), "v"(oo));
+          }
         }
       }
     }
     // ---------------- block 1 only: MaxPool1d(3,1,1) of the output rows (inception.py:99-104 reads it) ----------------
-    if constexpr (OUTK == 0) {
+    if constexpr (OUTK == 0 && !(TR_ABL & 4)) {
       // rows live on the 16 lanes of a DPP row: row-1 / row+1 are one lane away; the seam between the two
       // m-tiles (rows 15 | 16) takes the other accumulator.  torch keeps the FIRST maximum of (row-1, row, row+1).
       f32x4 p[2];
@@ -233,7 +242,7 @@ struct TrunkJobRun {
           const int o = (row + HALO) * TR_RSB + (OOFF + chb) * 2;
           *(uint2*)(img + o) = hv;
           *(uint2*)(img + TR_PB + o) = lv;
-          if constexpr (TRAIN) *(uint32_t*)(A.amax + ((R0 + (unsigned)row) * 128u + (unsigned)(OOFF + chb))) = code[mt];
+          if constexpr (TRAIN && !(TR_ABL & 1)) *(uint32_t*)(A.amax + ((R0 + (unsigned)row) * 128u + (unsigned)(OOFF + chb))) = code[mt];
         }
       }
     }

@@ -5,7 +5,7 @@
 //     step t : loaders : window t+1's dY(ACT2) regs -> LDS (masked with [ACT2 > 0] on the way, plus Flipout's
 //                        dz o s_out copy), window t+3's global loads issued (two loader waves alternate windows, so
 //                        every load has two steps to land).  The mask sources of the two stages (MID / ACT1 hi planes,
-//                        arg-max codes) go straight from HBM to the registers of the lanes that use them, one step ahead.
+//                        arg-max codes) are LDS-DMA'd by a third loader wave, two steps ahead, behind a counted vmcnt.
 //              stage A : dMID  = W6^T dz6 + W8^T dz8  (k3 / k5 level), masked with [MID > 0]      window t
 //              stage B : dACT1 = W4^T dz4 + W5^T dz5 + W7^T dz7 + scatter(W9^T dz9), masked       window t-1
 //   dz of MID never leaves LDS between the stages; both masked gradients are written once to HBM for the dW kernels
@@ -14,7 +14,13 @@
 #pragma once
 #include "kernels_trunk.h"
 
-enum { TX_NW = 12, TX_THREADS = TX_NW * 64 };   // 8 stage-B + 2 stage-A + 2 loader waves (3 per SIMD: 168 registers)
+// diagnostics builds only (tests/probes/ablate_gpu.sh): timing with parts of the kernel removed; results are wrong.
+// The product library is built with TX_ABL == 0: every `if constexpr` below folds away.
+#ifndef TX_ABL
+#define TX_ABL 0
+#endif
+
+enum { TX_NW = 15, TX_THREADS = TX_NW * 64, TX_NJ = 1 };   // 8 stage-B + 4 stage-A (TX_NJ tiles each) + 2 register loaders + 1 LDS-DMA loader
 enum {
   TX_RS2 = 176,                        // bytes per row of the dz(ACT2) image: 80 channels + 16 pad
   TX_P2 = IMG_ROWS * TX_RS2,           // 6,336
@@ -24,11 +30,16 @@ enum {
   TX_O_DZM = 3 * TX_SLOT,              // [2 bufs][dz(MID), dz(MID) o s_out]
   TX_O_SGN = TX_O_DZM + 2 * 2 * TX_PM, // [3 slots][80 words]
   TX_O_LUT = TX_O_SGN + 3 * 80 * 4,    // 256 x 16 B sign-byte -> XOR mask
-  TX_LDS = TX_O_LUT + 4096
+  // mask sources, LDS-DMA'd two steps ahead into a ring of 4: MID hi | ACT1 hi | arg-max codes (dense rows, 16-byte chunks
+  // XOR-swizzled by the row through the per-lane SOURCE address).  Not part of the zero fill: the DMA may land first.
+  TX_PD = 30 * 256, TX_PC = 30 * 128,
+  TX_DSLOT = 2 * TX_PD + TX_PC,
+  TX_O_DMA = TX_O_LUT + 4096,
+  TX_LDS = TX_O_DMA + 4 * TX_DSLOT
 };
 
 struct TrunkDxArgs {
-  const u16* g_act2;       // [S*B*L][80]  dY of ACT2 (from the dense layer's dX)
+  u16* g_act2;             // [S*B*L][80]  in: dY of ACT2 (from the dense layer's dX); out: masked with [ACT2 > 0] in place
   const u16* act2_hi;      // [S*B*L][80]
   const u16* mid_hi;       // [S*B*L][128]
   const u16* act1_hi;      // [S*B*L][128]
@@ -69,10 +80,55 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
   const int nsteps = nwin + 1;
   const uint4* lut = (const uint4*)(smem + TX_O_LUT);
 
-  if (wave >= 10) {
+  if (wave == 14) {
+    // =========================== LDS-DMA loader: mask sources ===========================
+    // step t issues MID hi of window t+3 and ACT1 hi + codes of window t+2, then waits until only the DMAs of this step
+    // and the previous one are in flight: what the stages read at step t+1 (MID hi of t+1, ACT1 hi / codes of t) landed.
+    const int nm = L * 16, nc = L * 8;
+    const int n_m = (nm + 63) >> 6, n_c = (nc + 63) >> 6;   // instructions per plane
+    const uint32_t lds0 = lds_addr(smem) + TX_O_DMA;
+    auto dma_plane = [&](const void* plane, long R0, int rowbytes, int lg, int n, int ninst, uint32_t dst) __attribute__((always_inline)) {
+      const int cm = (1 << lg) - 1;
+      for (int j = 0; j < ninst; ++j) {
+        const int q = j * 64 + lane;
+        const int row = q >> lg, pz = q & cm;
+        const int c = pz ^ (row & cm);
+        const char* src = (const char*)plane + (R0 + row) * rowbytes + c * 16;
+        if constexpr (!(TX_ABL & 4)) {
+          if (q < n) dma16(src, __builtin_amdgcn_readfirstlane(dst + (uint32_t)j * 1024u));
+        }
+      }
+    };
+    auto issue_mid = [&](int k) __attribute__((always_inline)) {
+      if (k < nwin) dma_plane(A.mid_hi, Rs + k * Rstep, 256, 4, nm, n_m, lds0 + (uint32_t)((k & 3) * TX_DSLOT));
+    };
+    auto issue_a1 = [&](int k) __attribute__((always_inline)) {
+      if (k < nwin) {
+        dma_plane(A.act1_hi, Rs + k * Rstep, 256, 4, nm, n_m, lds0 + (uint32_t)((k & 3) * TX_DSLOT + TX_PD));
+        dma_plane(A.amax, Rs + k * Rstep, 128, 3, nc, n_c, lds0 + (uint32_t)((k & 3) * TX_DSLOT + 2 * TX_PD));
+      }
+    };
+    const int per_mid = n_m, per_a1 = n_m + n_c;
+    // in-flight bookkeeping: number of DMA instructions issued in the current and the previous step
+    issue_mid(0); issue_a1(0); issue_mid(1); issue_a1(1); issue_mid(2);
+    int prev = (2 < nwin ? per_mid : 0);   // what may still fly after the prologue wait: MID hi of window 2
+    if constexpr (!(TX_ABL & 4)) BNN_WAIT_VMCNT_WIDE(prev);             // windows 0 / 1 landed
+    __syncthreads();
+    lds_barrier();
+    for (int t = 0; t < nsteps; ++t) {
+      issue_mid(t + 3);
+      issue_a1(t + 2);
+      const int cur = (t + 3 < nwin ? per_mid : 0) + (t + 2 < nwin ? per_a1 : 0);
+      if constexpr (!(TX_ABL & 4)) BNN_WAIT_VMCNT_WIDE(cur + prev);
+      prev = cur;
+      lds_barrier();
+    }
+    return;
+  }
+  if (wave >= 12) {
     // =========================== loaders ===========================
-    // wave 10 + p stages the windows k = p (mod 2): dz(ACT2) (+ its s_out copy) and the window's sign words
-    const int p = wave - 10;
+    // wave 12 + p stages the windows k = p (mod 2): dz(ACT2) (+ its s_out copy) and the window's sign words
+    const int p = wave - 12;
     const int n2 = L * 10;   // 16-byte chunks of an 80-channel bf16 plane
     const uint32_t* sg0 = nullptr;
     const uint32_t* sg1 = nullptr;
@@ -113,7 +169,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
       if (sg1) sb1 = sg1[(long)(K) * sst1];                                    \
     }                                                                          \
   } while (0)
-    auto put1 = [&](char* sl, int j, uint4 g, const uint4 y) {
+    auto put1 = [&](char* sl, char* gdst, int j, uint4 g, const uint4 y) __attribute__((always_inline)) {
       const int q = j * 64 + lane, qq = q < n2 ? q : 0;
       const int row = qq / 10, c = qq - row * 10;
       uint4 fm = make_uint4(0, 0, 0, 0);
@@ -130,6 +186,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         g.x &= relu_mask2(y.x); g.y &= relu_mask2(y.y); g.z &= relu_mask2(y.z); g.w &= relu_mask2(y.w);
         const int o = (row + HALO) * TX_RS2 + c * 16;
         *(uint4*)(sl + o) = g;
+        if constexpr (!(TX_ABL & 1)) *(uint4*)(gdst + q * 16) = g;   // the dW kernels read dz(ACT2) from HBM: masked once, here
         if constexpr (FO) *(uint4*)(sl + TX_P2 + o) = make_uint4(g.x ^ fm.x, g.y ^ fm.y, g.z ^ fm.z, g.w ^ fm.w);
       }
     };
@@ -141,8 +198,9 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
       sgw[lane] = sb0;                                                         \
       if (lane < 16) sgw[64 + lane] = sb1;                                     \
     }                                                                          \
-    put1(sl, 0, g0, y0); put1(sl, 1, g1, y1); put1(sl, 2, g2, y2);             \
-    put1(sl, 3, g3, y3); put1(sl, 4, g4_, y4);                                 \
+    char* gd = (char*)A.g_act2 + (Rs + (K) * Rstep) * 160;                     \
+    put1(sl, gd, 0, g0, y0); put1(sl, gd, 1, g1, y1); put1(sl, gd, 2, g2, y2); \
+    put1(sl, gd, 3, g3, y3); put1(sl, gd, 4, g4_, y4);                         \
   } while (0)
     // window k is fetched at the start of step k-3 (or in the prologue) and put during step k-1
     if (p < nwin) TX_FETCH(p);       // windows 0 / 1
@@ -152,7 +210,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
     lds_barrier();                   // window 0 staged
     for (int t = 0; t < nsteps; ++t) {
       const int k = t + 1;           // window to stage during this step
-      if ((k & 1) == p) {
+      if ((k & 1) == p && !(TX_ABL & 8)) {
         if (k < nwin) TX_PUT(k);
         if (k + 2 < nwin) TX_FETCH(k + 2);
       }
@@ -166,13 +224,13 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
   const int i16 = lane & 15, g4 = lane >> 4;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   if (wave >= 8) {
-    // =========================== stage A: dz(MID) tiles j (layer 6) and 4 + j (layer 8), j = 2 (wave - 8) + {0, 1} ===========================
-    const int jb = (wave - 8) * 2;
+    // =========================== stage A: dz(MID) tiles j (layer 6) and 4 + j (layer 8), j = TX_NJ (wave - 8) + jj ===========================
+    const int jb = (wave - 8) * TX_NJ;
     const LayerDesc l6 = A.layers[6], l8 = A.layers[8];
     const long sa = A.ws.slott_stride_a * s, sb = A.ws.slott_stride_b * s;
-    bf16x8 a6[2][2], b6[2][2], a8[2][3], b8[2][3];
+    bf16x8 a6[TX_NJ][2], b6[TX_NJ][2], a8[TX_NJ][3], b8[TX_NJ][3];
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
+    for (int jj = 0; jj < TX_NJ; ++jj) {
       const long r6 = (long)((jb + jj) * 16 + i16) * l6.KPt + l6.wt_off + g4 * 8;
       const long r8 = (long)((jb + jj) * 16 + i16) * l8.KPt + l8.wt_off + g4 * 8;
 #pragma unroll
@@ -188,37 +246,18 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
     }
     // B fragment of k-step ks: K index gg = ks*4 + g4 -> (flipped) tap gg >> 1, 8-cout chunk gg & 1
     const int lane_b = i16 * TX_RS2 + (g4 >> 1) * TX_RS2 + (g4 & 1) * 16;
-    // mask source [MID > 0] of this lane's outputs: [tile][half][m-tile] 4 channels, fetched one step ahead
-    uint2 ym[2][2][2];
-    auto load_y = [&](int k, uint2 (&y)[2][2][2]) {
-      // 32-bit byte offsets from the (uniform) plane base: one scalar base + one vector offset per access
-      const unsigned R0 = (unsigned)(Rs + k * Rstep);
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const unsigned row = (unsigned)min(mt * 16 + i16, L - 1);
-            y[jj][half][mt] = *(const uint2*)((const char*)A.mid_hi + ((R0 + row) * 256u + (unsigned)((half * 4 + jb + jj) * 32 + 8 * g4)));
-          }
-    };
-    if (nwin > 0) load_y(0, ym);
     __syncthreads();
     lds_barrier();
-    // The next window's mask source is requested at the END of a step, after this step's stores: hipcc waits with
-    // vmcnt(0) for a load that crossed the loop back-edge, which then covers nothing younger than the load itself, and
-    // the request has the barrier and the next MFMA phase to land.
     for (int t = 0; t < nsteps; ++t) {
       const int k = t;
-      uint2 (&cur)[2][2][2] = ym;
       if (k < nwin) {
         const char* sl = smem + TX_O_SLOT + (k % 3) * TX_SLOT;
         const uint32_t* sg = (const uint32_t*)(smem + TX_O_SGN) + (k % 3) * 80;
         const unsigned R0 = (unsigned)(Rs + k * Rstep);
         char* dzm = smem + TX_O_DZM + (k & 1) * 2 * TX_PM;
+        const char* dsl = smem + TX_O_DMA + (k & 3) * TX_DSLOT;   // MID hi of this window (LDS-DMA'd)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
+        for (int jj = 0; jj < TX_NJ; ++jj) {
           const int j = jb + jj;
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
@@ -233,6 +272,23 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
               const int ci = j * 16 + i16;   // input channel of the layer = row of the transposed fragment
               rsgn = ((sg[ly * 8 + (ci >> 5)] >> (ci & 31)) & 1u) ? 0x80008000u : 0u;
             }
+            // all operand reads of the tile first, then its MFMAs (one LDS latency per tile)
+            bf16x8 bz[3][2], bs[FO ? 3 : 1][2];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+              if (ks >= NKS) break;
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) {
+                // taps past the last one carry zero weights: keep their rows inside the image
+                const int off = (mt * 16 + ks * 2 - PAD + HALO) * TX_RS2 + CH0 * 16;
+                const int tap_hi = ks * 2 + 1;   // the tap of lanes g4 >= 2
+                const char* bp = sl + lane_b + off;
+                if (tap_hi >= TAPS) bp -= (g4 >> 1) * TX_RS2;
+                bz[ks][mt] = *(const bf16x8*)bp;
+                if constexpr (FO) bs[ks][mt] = *(const bf16x8*)(bp + TX_P2);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // reads first, then the MFMAs
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
               if (ks >= NKS) break;
@@ -241,17 +297,8 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
               if constexpr (FO) wb = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, wb) ^ u32x4{rsgn, rsgn, rsgn, rsgn});
 #pragma unroll
               for (int mt = 0; mt < 2; ++mt) {
-                // taps past the last one carry zero weights: keep their rows inside the image
-                const int off = (mt * 16 + ks * 2 - PAD + HALO) * TX_RS2 + CH0 * 16;
-                const int tap_hi = ks * 2 + 1;   // the tap of lanes g4 >= 2
-                const char* bp = sl + lane_b + off;
-                if (tap_hi >= TAPS) bp -= (g4 >> 1) * TX_RS2;
-                const bf16x8 bz = *(const bf16x8*)bp;
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bz, acc[mt], 0, 0, 0);
-                if constexpr (FO) {
-                  const bf16x8 bs = *(const bf16x8*)(bp + TX_P2);
-                  acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, bs, acc[mt], 0, 0, 0);
-                }
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bz[ks][mt], acc[mt], 0, 0, 0);
+                if constexpr (FO) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, bs[ks][mt], acc[mt], 0, 0, 0);
               }
             }
             // epilogue: mask with [MID > 0], dz -> LDS (+ s_out copy) and HBM
@@ -266,7 +313,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
             for (int mt = 0; mt < 2; ++mt) {
               const int row = mt * 16 + i16;
               if (row < L) {
-                const uint2 y = cur[jj][half][mt];
+                const uint2 y = *(const uint2*)(dsl + row * 256 + (((och >> 3) ^ (row & 15)) << 4) + (och & 7) * 2);
                 uint2 d = pack_bf4(acc[mt]);
                 d.x &= relu_mask2(y.x);
                 d.y &= relu_mask2(y.y);
@@ -276,13 +323,12 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
                   const uint32_t m0 = ((so & 1u) << 15) | ((so & 2u) << 30), m1 = ((so & 4u) << 13) | ((so & 8u) << 28);
                   *(uint2*)(dzm + TX_PM + o) = make_uint2(d.x ^ m0, d.y ^ m1);
                 }
-                *(uint2*)((char*)A.g_mid + ((R0 + (unsigned)row) * 256u + (unsigned)(och * 2))) = d;
+                if constexpr (!(TX_ABL & 1)) *(uint2*)((char*)A.g_mid + ((R0 + (unsigned)row) * 256u + (unsigned)(och * 2))) = d;
               }
             }
           }
         }
       }
-      if (k + 1 < nwin) load_y(k + 1, ym);
       lds_barrier();
     }
     return;
@@ -307,56 +353,56 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
     }
     const int och = ct * 16 + 4 * g4;
     const int ci = ct * 16 + i16;
-    // mask source [ACT1 > 0] and arg-max codes of this lane's outputs, fetched one step ahead
-    uint2 ya[2];
-    uint32_t cda[2];
-    auto load_y = [&](int k, uint2 (&y)[2], uint32_t (&cd)[2]) {
-      const unsigned R0 = (unsigned)(Rs + k * Rstep);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        const unsigned row = (unsigned)min(mt * 16 + i16, L - 1);
-        y[mt] = *(const uint2*)((const char*)A.act1_hi + ((R0 + row) * 256u + (unsigned)(och * 2)));
-        cd[mt] = *(const uint32_t*)(A.amax + ((R0 + row) * 128u + (unsigned)och));
-      }
-    };
-    ya[0] = ya[1] = make_uint2(0, 0);
-    cda[0] = cda[1] = 0;
     __syncthreads();
     lds_barrier();
-    for (int t = 0; t < nsteps; ++t) {   // loads of the next window at the END of the step (see stage A)
+    for (int t = 0; t < nsteps; ++t) {
       const int k = t - 1;
-      uint2 (&cy)[2] = ya;
-      uint32_t (&cc)[2] = cda;
       if (k >= 0 && k < nwin) {
         const char* sl = smem + TX_O_SLOT + (k % 3) * TX_SLOT;
         const uint32_t* sg = (const uint32_t*)(smem + TX_O_SGN) + (k % 3) * 80;
         const char* dzm = smem + TX_O_DZM + (k & 1) * 2 * TX_PM;
+        const char* dsl = smem + TX_O_DMA + (k & 3) * TX_DSLOT;   // ACT1 hi + codes of this window (LDS-DMA'd)
         const unsigned R0 = (unsigned)(Rs + k * Rstep);
         f32x4 acc[2], accp[2];
         acc[0] = acc[1] = accp[0] = accp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* b2 = sl + (i16 + HALO) * TX_RS2 + g4 * 16;
         const char* bm = dzm + (i16 + HALO) * TR_RSB + g4 * 16;
+        constexpr int lys[6] = {4, 5, 5, 7, 7, 9};
+        // all operand reads of an m-tile are issued before its MFMAs (one LDS latency per m-tile, not one per k-step)
+        bf16x8 w2[6];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-          constexpr int lys[6] = {4, 5, 5, 7, 7, 9};
-          bf16x8 w2 = wb[q];
+          w2[q] = wb[q];
           if constexpr (FO) {
             const uint32_t rsgn = ((sg[lys[q] * 8 + (ci >> 5)] >> (ci & 31)) & 1u) ? 0x80008000u : 0u;
-            w2 = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, w2) ^ u32x4{rsgn, rsgn, rsgn, rsgn});
+            w2[q] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, wb[q]) ^ u32x4{rsgn, rsgn, rsgn, rsgn});
           }
+        }
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const char* bp;
-            int second;
-            if (q == 0) { bp = b2 + mt * 16 * TX_RS2; second = TX_P2; }
-            else if (q == 5) { bp = b2 + mt * 16 * TX_RS2 + 6 * 16; second = TX_P2; }
-            else { bp = bm + mt * 16 * TR_RSB + (q - 1) * 64; second = TX_PM; }
-            const bf16x8 bz = *(const bf16x8*)bp;
-            f32x4& ta = q == 5 ? accp[mt] : acc[mt];
-            ta = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q], bz, ta, 0, 0, 0);
-            if constexpr (FO) {
-              const bf16x8 bs = *(const bf16x8*)(bp + second);
-              ta = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, bs, ta, 0, 0, 0);
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+          for (int qb = 0; qb < 6; qb += 3) {   // three k-steps per batch: 6 fragments in flight
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 bz[3], bs[FO ? 3 : 1];
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) {
+              const int q = qb + qq;
+              const char* bp;
+              int second;
+              if (q == 0) { bp = b2 + mt * 16 * TX_RS2; second = TX_P2; }
+              else if (q == 5) { bp = b2 + mt * 16 * TX_RS2 + 6 * 16; second = TX_P2; }
+              else { bp = bm + mt * 16 * TR_RSB + (q - 1) * 64; second = TX_PM; }
+              bz[qq] = *(const bf16x8*)bp;
+              if constexpr (FO) bs[qq] = *(const bf16x8*)(bp + second);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads together: hipcc otherwise sinks each one next to its MFMA
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) {
+              const int q = qb + qq;
+              f32x4& ta = q == 5 ? accp[mt] : acc[mt];
+              ta = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q], bz[qq], ta, 0, 0, 0);
+              if constexpr (FO) ta = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], bs[qq], ta, 0, 0, 0);
             }
           }
         }
@@ -366,7 +412,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         for (int mt = 0; mt < 2; ++mt) {
           const int row = mt * 16 + i16;
           v[mt] = acc[mt];
-          const uint32_t code = row < L ? cc[mt] : 0x01010101u;
+          const uint32_t code = row < L ? *(const uint32_t*)(dsl + 2 * TX_PD + row * 128 + (((och >> 4) ^ (row & 7)) << 4) + (och & 15)) : 0x01010101u;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint32_t cd = (code >> (8 * r)) & 3u;
@@ -388,15 +434,15 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         for (int mt = 0; mt < 2; ++mt) {
           const int row = mt * 16 + i16;
           if (row < L) {
-            const uint2 y = cy[mt];
+            const uint2 y = *(const uint2*)(dsl + TX_PD + row * 256 + (((och >> 3) ^ (row & 15)) << 4) + (och & 7) * 2);
             uint2 d = pack_bf4(v[mt]);
             d.x &= relu_mask2(y.x);
             d.y &= relu_mask2(y.y);
-            *(uint2*)((char*)A.g_act1 + ((R0 + (unsigned)row) * 256u + (unsigned)(och * 2))) = d;
+            if constexpr (!(TX_ABL & 1)) *(uint2*)((char*)A.g_act1 + ((R0 + (unsigned)row) * 256u + (unsigned)(och * 2))) = d;
+            else asm volatile("" ::"v"(d.x), "v"(d.y));
           }
         }
       }
-      if (t < nwin) load_y(t, ya, cda);
       lds_barrier();
     }
   }

@@ -255,3 +255,395 @@ __global__ __launch_bounds__(TW1_THREADS) void trunk_dw1_kernel(const TrunkDw1Ar
     default: dw1_role<EM, Dw1Job<EM, 3, 1, 0, 2, true>, Dw1Empty<EM>>(A, smem, s, nwin, lane); break;
   }
 }
+
+// ==========================================================================================
+// Block 2: trunk_dw2a_kernel (1x1 level: layers 4, 5, 7 and the pooled layer 9; X = ACT1 hi / its max-pool) and
+// trunk_dw2b_kernel (k3 / k5 level: layers 6, 8; X = MID hi).  dz comes pre-masked: dz(MID) from trunk_dx, dz(ACT2)
+// masked in place by trunk_dx's loader.
+// ==========================================================================================
+enum {
+  TW_PH = IMG_ROWS * 256,           // X image with halo rows: 36 x 128 channels
+  TW2A_SLOT = 2 * TW_PH + 2 * TW_PZ,   // ACT1 hi | pooled ACT1 hi | dz(MID) | dz(ACT2) (80 channels in a 128-channel image)
+  TW2A_O_SGN = 3 * TW2A_SLOT,          // [3 slots][6 layers 4..9][8 words]
+  TW2A_LDS = TW2A_O_SGN + 3 * 48 * 4,
+  TW2A_NC = 11, TW2A_NW = 15, TW2A_THREADS = TW2A_NW * 64,
+  TW2B_SLOT = TW_PH + TW_PZ,           // MID hi | dz(ACT2)
+  TW2B_O_SGN = 3 * TW2B_SLOT,
+  TW2B_LDS = TW2B_O_SGN + 3 * 48 * 4,
+  TW2B_NC = 4, TW2B_NW = 6, TW2B_THREADS = TW2B_NW * 64
+};
+
+struct TrunkDw2Args {
+  const u16* x_hi;         // [S*B*L][128]: ACT1 hi (a) or MID hi (b)
+  const u16* g_mid;        // [S*B*L][128] dz(MID) (a)
+  const u16* g_act2;       // [S*B*L][80]  dz(ACT2)
+  const LayerDesc* layers;
+  const uint32_t* sign_in;
+  const uint32_t* sign_out;
+  long examples;
+  float* gw_a; float* gw_b; float* gb_a;
+  long gw_stride; int gb_stride;
+  int S, B, L, nsplit;
+};
+
+// per-layer image geometry inside a slot (byte offset of the image, first channel)
+template <bool KA> __host__ __device__ constexpr int dw2_zoff(int l) { return KA ? ((l == 5 || l == 7) ? 2 * TW_PH : 2 * TW_PH + TW_PZ) : TW_PH; }
+__host__ __device__ constexpr int dw2_zch(int l) { return l == 7 ? 64 : (l == 9 ? 48 : (l == 6 ? 16 : (l == 8 ? 32 : 0))); }
+template <bool KA> __host__ __device__ constexpr int dw2_xoff(int l) { return (KA && l == 9) ? TW_PH : 0; }
+__host__ __device__ constexpr int dw2_xch(int l) { return l == 8 ? 64 : 0; }
+
+// one (layer, n-tile) job over the c-tiles [CT0, CT0 + NCT) of the layer's input channels, all taps
+template <int EM, bool KA, int LAYER, int NT, int CT0, int NCT, bool BIAS>
+struct Dw2Job {
+  static constexpr bool FO = (EM == EM_FLIPOUT);
+  static constexpr int TAPS = tl_taps(LAYER), PAD = (TAPS - 1) / 2;
+  f32x4 acc_a[TAPS][NCT], acc_b[FO ? TAPS : 1][FO ? NCT : 1], acc_bias;
+
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        acc_a[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (FO) acc_b[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    acc_bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  __device__ __forceinline__ void run(const char* sl, const uint32_t* sgs, int lane, bf16x8 ones) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int r0 = 8 * g + q;
+    const uint32_t* sg = sgs + (LAYER - 4) * 8;
+    constexpr int n0 = dw2_zch(LAYER) + NT * 16;
+    const char* zi = sl + dw2_zoff<KA>(LAYER);
+    const int ca = (n0 >> 3) + (p >> 1);
+    const char* a0 = zi + r0 * 256 + ((ca ^ f128(r0)) << 4) + 8 * (p & 1);
+    const char* a1 = zi + (r0 + 4) * 256 + ((ca ^ f128(r0 + 4)) << 4) + 8 * (p & 1);
+    const bf16x8 fa = tr_frag2(a0, a1);
+    bf16x8 fas = fa;
+    if constexpr (FO) {
+      constexpr int nb = NT * 16;
+      const bool no = (sg[4 + (nb >> 5)] >> ((nb & 31) + (lane & 15))) & 1u;
+      fas = xor_sign(fa, no);
+    }
+    if constexpr (BIAS) acc_bias = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, ones, acc_bias, 0, 0, 0);
+    const char* xi = sl + dw2_xoff<KA>(LAYER);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int ra = r0 + t - PAD + HALO, rb = ra + 4;
+      const int fa_ = f128(ra), fb_ = f128(rb);
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+          const int cb = ((dw2_xch(LAYER) + (CT0 + c) * 16) >> 3) + (p >> 1);
+        const char* b0 = xi + ra * 256 + ((cb ^ fa_) << 4) + 8 * (p & 1);
+        const char* b1 = xi + rb * 256 + ((cb ^ fb_) << 4) + 8 * (p & 1);
+        const bf16x8 fb = tr_frag2(b0, b1);
+        acc_a[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc_a[t][c], 0, 0, 0);
+        if constexpr (FO) {
+          const int cbit = (CT0 + c) * 16;   // bit of the layer's own input channel
+          const bool ni = (sg[cbit >> 5] >> ((cbit & 31) + (lane & 15))) & 1u;
+          acc_b[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fas, xor_sign(fb, ni), acc_b[t][c], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void flush(const TrunkDw2Args& A, int s, int lane) const {
+    const LayerDesc ly = A.layers[LAYER];
+    const int i4 = 4 * (lane >> 4), jc = lane & 15;
+    float* gwa = A.gw_a + A.gw_stride * s + ly.w_off;
+    float* gwb = A.gw_b + A.gw_stride * s + ly.w_off;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        const int ch = (CT0 + c) * 16 + jc;   // image channel of the layer's input
+        if (ly.cmap == CM_BLOCK && (ch % ly.cmap_b) >= ly.cmap_a) continue;   // block pads (27 -> 32) carry no weight
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = NT * 16 + i4 + r;
+          if (n >= ly.cout) continue;
+          const long o = (long)n * ly.KP + (long)t * ly.cin_img + ch;
+          atomicAdd(gwa + o, acc_a[t][c][r]);
+          if constexpr (FO) atomicAdd(gwb + o, acc_b[t][c][r]);
+        }
+      }
+    if constexpr (BIAS) {
+      if ((lane & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = NT * 16 + i4 + r;
+          if (n < ly.cout) atomicAdd(A.gb_a + (long)A.gb_stride * s + ly.bias_off + n, acc_bias[r]);
+        }
+      }
+    }
+  }
+};
+
+template <int EM, int SLOT, int O_SGN, class J0, class J1>
+__device__ __forceinline__ void dw2_role(const TrunkDw2Args& A, char* smem, int s, int nwin, int lane) {
+  J0 j0;
+  J1 j1;
+  j0.init();
+  j1.init();
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  __syncthreads();
+  lds_barrier();
+  for (int k = 0; k < nwin; ++k) {
+    const char* sl = smem + (k % 3) * SLOT;
+    const uint32_t* sg = (const uint32_t*)(smem + O_SGN) + (k % 3) * 48;
+    j0.run(sl, sg, lane, ones);
+    j1.run(sl, sg, lane, ones);
+    lds_barrier();
+  }
+  j0.flush(A, s, lane);
+  j1.flush(A, s, lane);
+}
+
+struct Dw2Empty {
+  __device__ __forceinline__ void init() {}
+  __device__ __forceinline__ void run(const char*, const uint32_t*, int, bf16x8) {}
+  __device__ __forceinline__ void flush(const TrunkDw2Args&, int, int) const {}
+};
+
+// sign words of layers 4..9 of one window: lane -> (layer = 4 + (lane >> 3), word k = lane & 7), lanes 0..47
+__device__ __forceinline__ void dw2_sign_setup(const TrunkDw2Args& A, int s, int split, int lane, const uint32_t*& p, long& stride) {
+  p = nullptr;
+  stride = 0;
+  if (lane >= 48) return;
+  const LayerDesc ly = A.layers[4 + (lane >> 3)];
+  const int kk = lane & 7;
+  if (kk < 4 && kk < ly.sign_in_words) {
+    p = A.sign_in + ly.sign_in_off * A.examples + ((long)s * A.B + split) * ly.sign_in_words + kk;
+    stride = (long)A.nsplit * ly.sign_in_words;
+  } else if (kk >= 4 && kk - 4 < ly.sign_out_words && kk < 6) {
+    p = A.sign_out + ly.sign_out_off * A.examples + ((long)s * A.B + split) * ly.sign_out_words + (kk - 4);
+    stride = (long)A.nsplit * ly.sign_out_words;
+  }
+}
+
+// packed max of non-negative bf16 pairs (ReLU outputs: the bit patterns order like the values)
+__device__ __forceinline__ uint32_t max2_bf16_pos(uint32_t a, uint32_t b) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+
+template <int EM>
+__global__ __launch_bounds__(TW2A_THREADS) void trunk_dw2a_kernel(const TrunkDw2Args A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x / A.nsplit, split = blockIdx.x - s * A.nsplit;
+  const int nwin = (A.B - split + A.nsplit - 1) / A.nsplit;
+  const int L = A.L;
+  {
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < TW2A_LDS / 4; k += TW2A_THREADS) z[k] = 0u;
+  }
+  if (wave >= TW2A_NC) {
+    // =========================== loaders: pair p stages the windows k = p (mod 2) ===========================
+    // role 0: ACT1 hi plane + its MaxPool1d(3,1,1) copy (built from the image it has just written: one wave, in-order
+    // LDS traffic); role 1: dz(MID), dz(ACT2), sign words
+    const int p = (wave - TW2A_NC) >> 1, lw = (wave - TW2A_NC) & 1;
+    const int nz = L * 16, n2 = L * 10;
+    auto wrow = [&](int k) __attribute__((always_inline)) { return ((long)s * A.B + split + (long)k * A.nsplit) * L; };
+    // window k: fetched at step k-3 (or in the prologue), put during step k-1; step k computes window k
+#define TW2_LOADER_LOOP(FETCH, PUT)          \
+  do {                                       \
+    if (p < nwin) FETCH(p);                  \
+    __syncthreads();                         \
+    if (p == 0 && nwin > 0) PUT(0);          \
+    if (p == 0 && 2 < nwin) FETCH(2);        \
+    lds_barrier();                           \
+    for (int t = 0; t < nwin; ++t) {         \
+      const int k = t + 1;                   \
+      if ((k & 1) == p) {                    \
+        if (k < nwin) PUT(k);                \
+        if (k + 2 < nwin) FETCH(k + 2);      \
+      }                                      \
+      lds_barrier();                         \
+    }                                        \
+  } while (0)
+    if (lw == 0) {
+      tr_u32x4 b[8];   // ext_vector registers (arrays of HIP's uint4 struct are not split into registers)
+      auto fetch = [&](int k) __attribute__((always_inline)) {
+        const char* src = (const char*)A.x_hi + wrow(k) * 256;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = j * 64 + lane, qq = q < nz ? q : 0;
+          b[j] = *(const tr_u32x4*)(src + qq * 16);
+        }
+      };
+      auto put = [&](int k) __attribute__((always_inline)) {
+        char* sl = smem + (k % 3) * TW2A_SLOT;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = j * 64 + lane;
+          const int ri = (q >> 4) + HALO, c = q & 15;
+          if (q < nz) *(tr_u32x4*)(sl + ri * 256 + ((c ^ f128(ri)) << 4)) = b[j];
+        }
+        // pooled copy: max over rows ri-1, ri, ri+1 (halo rows and rows >= L are zero; values are >= 0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = j * 64 + lane;
+          const int ri = (q >> 4) + HALO, c = q & 15;
+          if (q < nz) {
+            const tr_u32x4 u = *(const tr_u32x4*)(sl + (ri - 1) * 256 + ((c ^ f128(ri - 1)) << 4));
+            const tr_u32x4 d = *(const tr_u32x4*)(sl + (ri + 1) * 256 + ((c ^ f128(ri + 1)) << 4));
+            tr_u32x4 m = b[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = max2_bf16_pos(max2_bf16_pos(m[e], u[e]), d[e]);
+            *(tr_u32x4*)(sl + TW_PH + ri * 256 + ((c ^ f128(ri)) << 4)) = m;
+          }
+        }
+      };
+      TW2_LOADER_LOOP(fetch, put);
+    } else {
+      tr_u32x4 b[13];
+      uint32_t sw = 0;
+      const uint32_t* sgp;
+      long sgs;
+      dw2_sign_setup(A, s, split, lane, sgp, sgs);
+      auto fetch = [&](int k) __attribute__((always_inline)) {
+        const long R0 = wrow(k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = j * 64 + lane, qq = q < nz ? q : 0;
+          b[j] = *(const tr_u32x4*)((const char*)A.g_mid + R0 * 256 + qq * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int q = j * 64 + lane, qq = q < n2 ? q : 0;
+          b[8 + j] = *(const tr_u32x4*)((const char*)A.g_act2 + R0 * 160 + qq * 16);
+        }
+        if constexpr (FO) {
+          if (sgp) sw = sgp[(long)k * sgs];
+        }
+      };
+      auto put = [&](int k) __attribute__((always_inline)) {
+        char* sl = smem + (k % 3) * TW2A_SLOT;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int q = j * 64 + lane;
+          const int row = q >> 4, c = q & 15;
+          if (q < nz) *(tr_u32x4*)(sl + 2 * TW_PH + row * 256 + ((c ^ f128(row)) << 4)) = b[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const int q = j * 64 + lane;
+          const int row = q / 10, c = q - row * 10;
+          if (q < n2) *(tr_u32x4*)(sl + 2 * TW_PH + TW_PZ + row * 256 + ((c ^ f128(row)) << 4)) = b[8 + j];
+        }
+        if constexpr (FO) {
+          if (lane < 48) ((uint32_t*)(smem + TW2A_O_SGN))[(k % 3) * 48 + lane] = sw;
+        }
+      };
+      TW2_LOADER_LOOP(fetch, put);
+    }
+    return;
+  }
+#define DW2A_ROLE(LY, NT) dw2_role<EM, TW2A_SLOT, TW2A_O_SGN, Dw2Job<EM, true, LY, NT, 0, 8, true>, Dw2Empty>(A, smem, s, nwin, lane)
+  switch (wave) {
+    case 0: DW2A_ROLE(4, 0); break;
+    case 1: DW2A_ROLE(5, 0); break;
+    case 2: DW2A_ROLE(5, 1); break;
+    case 3: DW2A_ROLE(5, 2); break;
+    case 4: DW2A_ROLE(5, 3); break;
+    case 5: DW2A_ROLE(7, 0); break;
+    case 6: DW2A_ROLE(7, 1); break;
+    case 7: DW2A_ROLE(7, 2); break;
+    case 8: DW2A_ROLE(7, 3); break;
+    case 9: DW2A_ROLE(9, 0); break;
+    default: DW2A_ROLE(9, 1); break;
+  }
+#undef DW2A_ROLE
+}
+
+template <int EM>
+__global__ __launch_bounds__(TW2B_THREADS) void trunk_dw2b_kernel(const TrunkDw2Args A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x / A.nsplit, split = blockIdx.x - s * A.nsplit;
+  const int nwin = (A.B - split + A.nsplit - 1) / A.nsplit;
+  const int L = A.L;
+  {
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < TW2B_LDS / 4; k += TW2B_THREADS) z[k] = 0u;
+  }
+  if (wave >= TW2B_NC) {
+    // loader wave 4 + p stages the windows k = p (mod 2): MID hi, dz(ACT2), sign words
+    const int p = wave - TW2B_NC;
+    const int nz = L * 16, n2 = L * 10;
+    tr_u32x4 b[13];   // ext_vector registers (arrays of HIP's uint4 struct are not split into registers)
+    uint32_t sw = 0;
+    const uint32_t* sgp;
+    long sgs;
+    dw2_sign_setup(A, s, split, lane, sgp, sgs);
+    auto fetch = [&](int k) __attribute__((always_inline)) {
+      const long R0 = ((long)s * A.B + split + (long)k * A.nsplit) * L;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = j * 64 + lane, qq = q < nz ? q : 0;
+        b[j] = *(const tr_u32x4*)((const char*)A.x_hi + R0 * 256 + qq * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int q = j * 64 + lane, qq = q < n2 ? q : 0;
+        b[8 + j] = *(const tr_u32x4*)((const char*)A.g_act2 + R0 * 160 + qq * 16);
+      }
+      if constexpr (FO) {
+        if (sgp) sw = sgp[(long)k * sgs];
+      }
+    };
+    auto put = [&](int k) __attribute__((always_inline)) {
+      char* sl = smem + (k % 3) * TW2B_SLOT;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = j * 64 + lane;
+        if (q < nz) {
+          const int ri = (q >> 4) + HALO, c = q & 15;
+          *(tr_u32x4*)(sl + ri * 256 + ((c ^ f128(ri)) << 4)) = b[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int q = j * 64 + lane;
+        if (q < n2) {
+          const int row = q / 10, c = q - row * 10;
+          *(tr_u32x4*)(sl + TW_PH + row * 256 + ((c ^ f128(row)) << 4)) = b[8 + j];
+        }
+      }
+      if constexpr (FO) {
+        if (lane < 48) ((uint32_t*)(smem + TW2B_O_SGN))[(k % 3) * 48 + lane] = sw;
+      }
+    };
+    if (p < nwin) fetch(p);
+    __syncthreads();
+    if (p == 0 && nwin > 0) put(0);
+    if (p == 0 && 2 < nwin) fetch(2);
+    lds_barrier();
+    for (int t = 0; t < nwin; ++t) {
+      const int k = t + 1;
+      if ((k & 1) == p) {
+        if (k < nwin) put(k);
+        if (k + 2 < nwin) fetch(k + 2);
+      }
+      lds_barrier();
+    }
+    return;
+  }
+  // wave j: c-tile j of both layers (k3: 3 tiles, k5: 5 tiles); wave 0 also owns the bias sums
+#define DW2B_ROLE(CT, BS) dw2_role<EM, TW2B_SLOT, TW2B_O_SGN, Dw2Job<EM, false, 6, 0, CT, 1, BS>, Dw2Job<EM, false, 8, 0, CT, 1, BS>>(A, smem, s, nwin, lane)
+  switch (wave) {
+    case 0: DW2B_ROLE(0, true); break;
+    case 1: DW2B_ROLE(1, false); break;
+    case 2: DW2B_ROLE(2, false); break;
+    default: DW2B_ROLE(3, false); break;
+  }
+#undef DW2B_ROLE
+}

@@ -1338,12 +1338,48 @@ static int launch_trunk_dw1(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   return 0;
 }
 
+// dW of block 2 (kernels_trunk_dw.h): kind 0 = 1x1 level (layers 4, 5, 7, 9), kind 1 = k3 / k5 level (layers 6, 8)
+static int launch_trunk_dw2(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int kind) {
+  GroupArgs G;
+  fill_group_args(p, a, c, kind == 0 ? 1 : 2, a->x, &G);
+  TrunkDw2Args T{};
+  T.x_hi = (const u16*)tens_ref(p, kind == 0 ? TI_ACT1 : TI_MID, 0).p;
+  T.g_mid = (const u16*)tens_ref(p, TI_MID, 1).p;
+  T.g_act2 = (const u16*)tens_ref(p, TI_ACT2, 1).p;
+  T.layers = G.layers;
+  T.sign_in = c->nz.sign_in;
+  T.sign_out = c->nz.sign_out;
+  T.examples = (long)c->S * c->B;
+  T.gw_a = G.gw_a; T.gw_b = G.gw_b; T.gb_a = G.gb_a;
+  T.gw_stride = G.gw_stride; T.gb_stride = G.gb_stride;
+  T.S = c->S; T.B = c->B; T.L = p->d.win_length;
+  // kind 1 workgroups are small (6 waves, 52 KB of LDS): two share a CU
+  T.nsplit = std::max(1, std::min(c->B, (kind == 0 ? 256 : 512) / std::max(1, c->S)));
+  const unsigned grid = (unsigned)(c->S * T.nsplit);
+  ProfScope ps_(&p->prof, PK_DW, kind == 0 ? 1 : 2, c->st);
+  ps_.name(kind == 0 ? "trunk_dw2a_kernel<%d>" : "trunk_dw2b_kernel<%d>", c->em);
+  if (kind == 0) {
+    if (c->em == EM_FLIPOUT) {
+      BNN_TRY(set_lds(trunk_dw2a_kernel<EM_FLIPOUT>, TW2A_LDS));
+      trunk_dw2a_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TW2A_THREADS), TW2A_LDS, c->st>>>(T);
+    } else {
+      BNN_TRY(set_lds(trunk_dw2a_kernel<EM_PLAIN>, TW2A_LDS));
+      trunk_dw2a_kernel<EM_PLAIN><<<dim3(grid), dim3(TW2A_THREADS), TW2A_LDS, c->st>>>(T);
+    }
+  } else {
+    if (c->em == EM_FLIPOUT) trunk_dw2b_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TW2B_THREADS), TW2B_LDS, c->st>>>(T);
+    else trunk_dw2b_kernel<EM_PLAIN><<<dim3(grid), dim3(TW2B_THREADS), TW2B_LDS, c->st>>>(T);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // fused conv-trunk dX (kernels_trunk_bwd.h): dz of MID and of ACT1 from dY(ACT2), groups 2 and 1 in one launch
 static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   GroupArgs G;
   fill_group_args(p, a, c, 1, a->x, &G);
   TrunkDxArgs T{};
-  T.g_act2 = (const u16*)tens_ref(p, TI_ACT2, 1).p;
+  T.g_act2 = (u16*)tens_ref(p, TI_ACT2, 1).p;
   T.act2_hi = (const u16*)tens_ref(p, TI_ACT2, 0).p;
   T.mid_hi = (const u16*)tens_ref(p, TI_MID, 0).p;
   T.act1_hi = (const u16*)tens_ref(p, TI_ACT1, 0).p;
@@ -1433,10 +1469,20 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
     A.dbg = dbg_for(p, PK_DW, gi);
+    if (!A.g.is_dense && trunk_ok(p, c)) {
+      // conv trunk: dz of MID / ACT1 (and the masked dz of ACT2) first, then the three dW kernels
+      if (gi == 2) {
+        BNN_TRY(launch_trunk_dx(p, a, c));
+        BNN_TRY(launch_trunk_dw2(p, a, c, 1));
+      } else if (gi == 1) {
+        BNN_TRY(launch_trunk_dw2(p, a, c, 0));
+      } else {
+        BNN_TRY(launch_trunk_dw1(p, a, c));
+      }
+      continue;
+    }
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
-    else if (!A.g.is_dense && gi == 0 && trunk_ok(p, c))
-      BNN_TRY(launch_trunk_dw1(p, a, c));
     else if (!A.g.is_dense)
       BNN_TRY(launch_conv_dw_mw(A, p->layers, c->em, c->st, &p->prof, gi));
     else if (A.g.n_branch == 1 && !A.g.in_bcast && A.g.br[0].cout <= 64 && (A.g.br[0].cout % 8) == 0 &&
@@ -1451,11 +1497,6 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       (A.g.br[b].pool ? any_pool : any_direct) = true;
     }
     const bool conv_bf = p->d.prec == BNN_PREC_BF16X3 && !A.g.is_dense;
-    if (conv_bf && trunk_ok(p, c)) {
-      // groups 2 and 1: one fused launch once dY(ACT2) is complete (the dense layer's dX ran before group 2)
-      if (gi == 2) BNN_TRY(launch_trunk_dx(p, a, c));
-      continue;
-    }
     if (conv_bf && (any_direct || any_pool)) {
       // one launch: direct and pooled branches, arg-max scatter included
       A.dbg = dbg_for(p, PK_DX, gi);
