@@ -23,7 +23,7 @@ EXPORTS = [
     "bnn_plan_bind", "bnn_plan_site", "bnn_plan_layer", "bnn_plan_tensor", "bnn_sample_weights",
     "bnn_forward", "bnn_head_nll", "bnn_backward", "bnn_grad_finalize", "bnn_clipped_adam",
     "bnn_elbo_step", "bnn_elbo_evaluate", "bnn_predict", "bnn_export_noise", "bnn_profile_enable",
-    "bnn_profile_select", "bnn_profile_name", "bnn_profile_read", "bnn_gather_windows",
+    "bnn_profile_select", "bnn_profile_name", "bnn_profile_read", "bnn_gather_windows", "bnn_det_step",
 ]
 
 
@@ -54,14 +54,20 @@ class ElboArgs(C.Structure):
 class AdamArgs(C.Structure):
     _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("clip_norm", C.c_double), ("weight_decay", C.c_double), ("step", C.c_int64),
-                ("grad_scale", C.c_double)]
+                ("grad_scale", C.c_double), ("freeze_loc", C.c_int32), ("freeze_scale", C.c_int32),
+                ("torch_eps", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ElboOut(C.Structure):
     _fields_ = [("loss", C.c_void_p), ("kl", C.c_void_p), ("loglik", C.c_void_p), ("preds", C.c_void_p)]
 
 
-_ABI_STRUCTS = [PlanDesc, Buffers, Noise, ElboArgs, AdamArgs, ElboOut]
+class DetArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("batch", C.c_int32), ("objective", C.c_int32)]
+
+
+_ABI_STRUCTS = [PlanDesc, Buffers, Noise, ElboArgs, AdamArgs, ElboOut, DetArgs]
+ABI_VERSION = 2
 _lib: Optional[C.CDLL] = None
 
 
@@ -95,6 +101,8 @@ def load() -> C.CDLL:
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise NativeError(f"{LIB_PATH} does not export {name}")
+    if lib.bnn_version() != ABI_VERSION:
+        raise NativeError(f"{LIB_PATH} has ABI version {lib.bnn_version()}, the binding expects {ABI_VERSION}: rebuild it")
     for i, st in enumerate(_ABI_STRUCTS):
         n = lib.bnn_abi_sizeof(i)
         if n != C.sizeof(st):

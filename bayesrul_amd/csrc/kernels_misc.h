@@ -321,6 +321,7 @@ struct HeadArgs {
   double* ll_acc;   // [S]
   int S, B;
   int with_obs;
+  int objective;    // 0: TyXe HeteroskedasticGaussian (A11); 1: HNN gaussian_nll_loss; 2: NN mse  (frequentist.py:39-48,173-178)
 };
 
 __global__ void head_nll_kernel(const HeadArgs A) {
@@ -337,7 +338,24 @@ __global__ void head_nll_kernel(const HeadArgs A) {
       A.preds[r * 2] = o0;
       A.preds[r * 2 + 1] = o1;
     }
-    if (A.with_obs) {
+    if (A.with_obs && A.objective != 0) {
+      // frequentist siblings: ll = -loss_b; scale = o1 (the net's own softplus + threshold only)
+      const float d = o0 - A.y[idx];
+      float g0, g1 = 0.f;
+      if (A.objective == 1) {
+        const float var = fmaxf(o1 * o1, 1e-6f);   // F.gaussian_nll_loss: var.clamp_(min=eps) under no_grad
+        ll = -0.5 * ((double)logf(var) + (double)(d * d) / (double)var);
+        g0 = d / var;
+        g1 = (0.5f / var - 0.5f * d * d / (var * var)) * 2.f * o1;   // the clamp carries no gradient: d var / d o1 = 2 o1
+      } else {
+        ll = -(double)(d * d);
+        g0 = 2.f * d;
+      }
+      if (A.dz) {
+        A.dz[r * 2] = p0 ? g0 * dsoftplus_t(z0) : 0.f;
+        A.dz[r * 2 + 1] = p1 ? g1 * dsoftplus_t(z1) : 0.f;
+      }
+    } else if (A.with_obs) {
       const float sc = softplus_t(o1);
       const float d = A.y[idx] - o0;
       ll = -(double)(d * d) / (2.0 * (double)sc * (double)sc) - (double)logf(sc) - 0.9189385332046727;
@@ -372,6 +390,7 @@ struct LossArgs {
   int S;
   int radial;
   double c, n_over_b;
+  double kl_weight;   // 1: ELBO; 0: the frequentist objectives (loss = -c * n_over_b * ll)
   float* loss; float* kl; float* ll;
   float* grad_tail;  // &grad[2P] or null
 };
@@ -385,7 +404,7 @@ __global__ void finish_loss_kernel(const LossArgs A) {
   }
   kl /= A.S;
   ll /= A.S;
-  const double loss = A.c * kl - A.c * A.n_over_b * ll;
+  const double loss = A.kl_weight * A.c * kl - A.c * A.n_over_b * ll;
   if (A.loss) *A.loss = (float)loss;
   if (A.kl) *A.kl = (float)kl;
   if (A.ll) *A.ll = (float)ll;
@@ -484,11 +503,13 @@ struct AdamArgs {
   float* mu; float* rho; float* m; float* v; const float* grad;
   long P;
   float lr, beta1, beta2, eps, clip, wd, step_size, grad_scale;
+  int freeze_loc, freeze_scale;
 };
 
 __global__ void clipped_adam_kernel(const AdamArgs A) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * A.P) return;
+  if (i < A.P ? A.freeze_loc : A.freeze_scale) return;
   float* p = i < A.P ? A.mu + i : A.rho + (i - A.P);
   float g = A.grad[i] * A.grad_scale;
   g = fminf(fmaxf(g, -A.clip), A.clip);
@@ -575,16 +596,17 @@ __global__ void predict_finish_kernel(const float* preds /*[S][B][2]*/, int B, i
 // feature_major = 1: a stored window is the reference's LMDB value, [F][W] fp32 (data/lmdb_utils.py:190-191 reads
 // it with reshape(n_features, -1).T), and is transposed to the [W][F] the step consumes.
 // ------------------------------------------------------------------------------------------
-__global__ void gather_windows_kernel(const float* x_all, const float* y_all, const long* idx, long n, int W, int F,
-                                      int feature_major, float* x_out, float* y_out) {
+__global__ void gather_windows_kernel(const float* x_all, const float* y_all, const long* idx, long n, long n_windows, int W,
+                                      int F, int feature_major, float* x_out, float* y_out) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int wf = W * F;
   if (e >= n * wf) return;
   const long i = e / wf;
   const int r = (int)(e - i * wf);
   const long j = idx[i];
+  const bool ok = j >= 0 && j < n_windows;   // a bad index is never dereferenced: NaN marks it
   const int w = r / F, f = r - w * F;
-  x_out[e] = x_all[j * wf + (feature_major ? f * W + w : r)];
-  if (r == 0 && y_all) y_out[i] = y_all[j];
+  x_out[e] = ok ? x_all[j * wf + (feature_major ? f * W + w : r)] : __int_as_float(0x7fc00000);
+  if (r == 0 && y_all) y_out[i] = ok ? y_all[j] : __int_as_float(0x7fc00000);
 }
 

@@ -435,6 +435,7 @@ extern "C" size_t bnn_abi_sizeof(int which) {
     case 3: return sizeof(BnnElboArgs);
     case 4: return sizeof(BnnAdamArgs);
     case 5: return sizeof(BnnElboOut);
+    case 6: return sizeof(BnnDetArgs);
   }
   return 0;
 }
@@ -556,6 +557,7 @@ struct Ctx {
   const float* eps_w = nullptr;
   const float* rad_r = nullptr;
   float c, scale_ll, n_over_b;
+  int objective = 0;   // 0 ELBO; 1 / 2: frequentist objectives (bnn_det_step)
   NoiseRefs nz{};
   int s_base = 0;  // particle offset for noise streams (predict chunks)
 };
@@ -1448,6 +1450,7 @@ static int do_head(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, float* preds,
   H.S = c->S;
   H.B = c->B;
   H.with_obs = a->with_obs && a->y;
+  H.objective = c->objective;
   ProfScope ps_(&p->prof, PK_HEAD, 0, c->st);
   head_nll_kernel<<<dim3((c->B + 255) / 256, c->S), dim3(256), 0, c->st>>>(H);
   HIP_TRY(hipGetLastError());
@@ -1571,6 +1574,7 @@ static int do_loss(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElbo
   LA.radial = c->radial;
   LA.c = c->c;
   LA.n_over_b = a->with_obs ? c->n_over_b : 0.0;
+  LA.kl_weight = c->objective ? 0.0 : 1.0;
   float* scal = ws_f(p, p->o_scal);
   LA.loss = (out && out->loss) ? out->loss : scal;
   LA.kl = (out && out->kl) ? out->kl : scal + 1;
@@ -1600,6 +1604,10 @@ static int do_adam(BnnPlan* p, const BnnAdamArgs* ad, hipStream_t st) {
   const double bc2 = 1.0 - std::pow(ad->beta2, (double)ad->step);
   A.step_size = (float)(ad->lr * std::sqrt(bc2) / bc1);
   A.grad_scale = (float)(ad->grad_scale == 0.0 ? 1.0 : ad->grad_scale);
+  A.freeze_loc = ad->freeze_loc;
+  A.freeze_scale = ad->freeze_scale;
+  // torch.optim.Adam: p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)  ==  step_size * m / (sqrt(v) + eps * sqrt(bc2))
+  if (ad->torch_eps) A.eps = (float)(ad->eps * std::sqrt(bc2));
   ProfScope ps_(&p->prof, PK_ADAM, 0, st);
   clipped_adam_kernel<<<dim3((unsigned)((2 * p->P + 255) / 256)), dim3(256), 0, st>>>(A);
   HIP_TRY(hipGetLastError());
@@ -1665,6 +1673,48 @@ extern "C" int bnn_elbo_step(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* n
   BNN_TRY(do_backward(p, a, &c));
   BNN_TRY(do_finalize(p, a, &c));
   BNN_TRY(do_loss(p, a, &c, out, true));
+  if (adam) BNN_TRY(do_adam(p, adam, c.st));
+  return 0;
+}
+
+// frequentist siblings (frequentist.py:39-48,173-178) on the plain-contraction kernels: weights = mu (zero noise), no KL
+extern "C" int bnn_det_step(BnnPlan* p, const BnnDetArgs* d, const BnnAdamArgs* adam, const BnnElboOut* out, void* stream) {
+  if (!p || !d) return fail(BNN_E_INVALID, "null argument");
+  if (d->objective != 1 && d->objective != 2) return fail(BNN_E_INVALID, "objective must be 1 (gaussian NLL) or 2 (MSE)");
+  if (!d->x || !d->y) return fail(BNN_E_INVALID, "x / y must be set");
+  BnnElboArgs a{};
+  a.x = d->x;
+  a.y = d->y;
+  a.batch = d->batch;
+  a.particles = 1;
+  a.global_batch = d->batch;
+  a.dataset_size = (double)d->batch;   // N / B = 1: the likelihood term is a plain sum over the batch
+  a.prior_loc = 0.0;
+  a.prior_scale = 1.0;
+  a.mode_override = BNN_MODE_NORMAL;
+  a.with_obs = 1;
+  a.scaled = 0;
+  Ctx c;
+  BNN_TRY(make_ctx(p, &a, nullptr, stream, true, &c));
+  c.objective = d->objective;
+  c.c = (float)(1.0 / d->batch);   // mean over the batch ...
+  c.n_over_b = 1.f;
+  c.scale_ll = (float)(1.0 / d->batch);
+  // weights = mu: the weight noise of the one particle is zero
+  float* eps = ws_f(p, p->o_eps);
+  HIP_TRY(hipMemsetAsync(eps, 0, (size_t)p->P * 4, c.st));
+  BnnNoise nz{};
+  nz.eps_w = eps;
+  BNN_TRY(prepare_noise(p, &a, &nz, &c));
+  BNN_TRY(do_sample(p, &a, &c));
+  BNN_TRY(do_forward(p, &a, &c, a.x));
+  BNN_TRY(do_head(p, &a, &c, out ? out->preds : nullptr, true));
+  BNN_TRY(do_backward(p, &a, &c));
+  const float c_kl = c.c;
+  c.c = 0.f;   // ... and no KL / prior term in the gradient
+  BNN_TRY(do_finalize(p, &a, &c));
+  c.c = c_kl;
+  BNN_TRY(do_loss(p, &a, &c, out, true));
   if (adam) BNN_TRY(do_adam(p, adam, c.st));
   return 0;
 }
@@ -1793,14 +1843,15 @@ extern "C" int bnn_profile_enable(BnnPlan* p, int on) {
 // window store (data feed): x_out[i] = window idx[i] of an HBM-resident set, y_out[i] = its label.  Replaces the
 // per-item reads of LmdbDataset.__getitem__ (data/lmdb_utils.py:184-194) + NCMAPSSLmdbDataset.__getitem__
 // (data/ncmapss/dataset.py:13-16) + the DataLoader collate for a whole batch.
-extern "C" int bnn_gather_windows(const float* x_all, const float* y_all, const int64_t* idx, int64_t n, int32_t win_length,
-                                  int32_t n_features, int32_t feature_major, float* x_out, float* y_out, void* stream) {
-  if (n < 0 || win_length <= 0 || n_features <= 0) return fail(BNN_E_INVALID, "bad geometry");
+extern "C" int bnn_gather_windows(const float* x_all, const float* y_all, const int64_t* idx, int64_t n, int64_t n_windows,
+                                  int32_t win_length, int32_t n_features, int32_t feature_major, float* x_out, float* y_out,
+                                  void* stream) {
+  if (n < 0 || n_windows < 0 || win_length <= 0 || n_features <= 0) return fail(BNN_E_INVALID, "bad geometry");
   if (n == 0) return 0;   // an empty batch carries no buffers
   if (!x_all || !idx || !x_out || (y_all && !y_out)) return fail(BNN_E_INVALID, "null argument");
   const long total = (long)n * win_length * n_features;
   gather_windows_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-      x_all, y_all, (const long*)idx, (long)n, win_length, n_features, feature_major, x_out, y_out);
+      x_all, y_all, (const long*)idx, (long)n, (long)n_windows, win_length, n_features, feature_major, x_out, y_out);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -70,7 +70,7 @@ class DeviceWindowStore:
             st = torch.cuda.current_stream(self.device).cuda_stream
             N.check(self.lib.bnn_gather_windows(
                 C.c_void_p(self.x.data_ptr()), C.c_void_p(N.ptr(self.y)), C.c_void_p(idx.data_ptr()), C.c_int64(b),
-                C.c_int32(self.W), C.c_int32(self.F), C.c_int32(int(self.feature_major)), C.c_void_p(xo.data_ptr()),
+                C.c_int64(self.n), C.c_int32(self.W), C.c_int32(self.F), C.c_int32(int(self.feature_major)), C.c_void_p(xo.data_ptr()),
                 C.c_void_p(N.ptr(yo)), C.c_void_p(st)))
         return xo, yo
 

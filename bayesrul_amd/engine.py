@@ -43,6 +43,9 @@ class AdamHyper:
     clip_norm: float = 15.0
     lrd: float = 1.0
     weight_decay: float = 0.0
+    train_loc: bool = True     # guide options of guides/radial.py:74-94 (False: the parameter is left untouched)
+    train_scale: bool = True
+    torch_eps: bool = False    # torch.optim.Adam's epsilon placement (the frequentist siblings)
 
 
 @dataclass
@@ -154,7 +157,7 @@ class SviEngine:
     def state_dict(self) -> Dict[str, torch.Tensor]:
         return {"mu": self.mu.detach().cpu(), "rho": self.rho.detach().cpu(), "adam_m": self.adam_m.detach().cpu(),
                 "adam_v": self.adam_v.detach().cpu(), "t": torch.tensor(self.t),
-                "lr": torch.tensor(-1.0 if self.lr is None else self.lr)}
+                "lr": torch.tensor(-1.0 if self.lr is None else self.lr, dtype=torch.float64)}
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
         with torch.no_grad():
@@ -243,7 +246,8 @@ class SviEngine:
             self.lr = h.lr
         self.t += 1
         self.lr *= h.lrd  # pyro ClippedAdam decays lr at the top of step()
-        return N.AdamArgs(self.lr, h.betas[0], h.betas[1], h.eps, h.clip_norm, h.weight_decay, self.t, grad_scale)
+        return N.AdamArgs(self.lr, h.betas[0], h.betas[1], h.eps, h.clip_norm, h.weight_decay, self.t, grad_scale,
+                          int(not h.train_loc), int(not h.train_scale), int(h.torch_eps), 0)
 
     # ---------------------------------------------------------------- the path
     def step(self, x: torch.Tensor, y: torch.Tensor, particles: int, dataset_size: float, prior_loc: float,
@@ -264,6 +268,24 @@ class SviEngine:
                                            C.byref(out), C.c_void_p(self._stream())))
             res = self._scal[:3].clone()
         return (res, preds) if want_preds else res
+
+    def det_step(self, x: torch.Tensor, y: torch.Tensor, objective: str, adam: Optional[AdamHyper],
+                 want_preds: bool = True):
+        """One deterministic training step of the net with weights = mu (the frequentist siblings, SURVEY.md 8(f) rank
+        4): `objective` = "gaussian_nll" (HNN.step, frequentist.py:39-48) or "mse" (NN.step, :173-178).  Returns the
+        mean loss as a 1-element device tensor and the net outputs [B, 2]; d loss / d mu is left in grad[:P]."""
+        obj = {"gaussian_nll": 1, "mse": 2}[objective]
+        with torch.cuda.device(self.device):
+            assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and y.is_cuda and y.dtype == torch.float32
+            B = x.shape[0]
+            d = N.DetArgs(x.data_ptr(), y.data_ptr(), B, obj)
+            preds = torch.empty(1, B, 2, dtype=torch.float32, device=self.device) if want_preds else None
+            out = N.ElboOut(self._scal.data_ptr(), self._scal.data_ptr() + 4, self._scal.data_ptr() + 8, N.ptr(preds))
+            ad = self._adam_args(adam, 1.0) if adam is not None else None
+            N.check(self.lib.bnn_det_step(self._plan, C.byref(d), C.byref(ad) if ad else None, C.byref(out),
+                                          C.c_void_p(self._stream())))
+            loss = self._scal[:1].clone()
+        return loss, (preds[0] if want_preds else None)
 
     def apply_adam(self, adam: AdamHyper, grad_scale: float = 1.0) -> None:
         with torch.cuda.device(self.device):

@@ -57,6 +57,19 @@ class LightningModuleLite(torch.nn.Module):
         return out
 
 
+class _Progress:
+    """optim_step_progress of Lightning's manual-optimisation loop (what bayesian.py:144,156 pokes)."""
+
+    def __init__(self):
+        self.ready = self.completed = 0
+
+    def increment_ready(self):
+        self.ready += 1
+
+    def increment_completed(self):
+        self.completed += 1
+
+
 class Trainer:
     """fit / validate / test / predict loops over the BNN hooks (single device, like the
     reference's `devices: 1`, conf/trainer/default.yaml:8-12)."""
@@ -67,6 +80,9 @@ class Trainer:
         self.monitor, self.patience = monitor, patience
         self.history: List[Dict[str, float]] = []
         self.global_step = 0
+        progress = _Progress()
+        self.fit_loop = SimpleNamespace(epoch_loop=SimpleNamespace(batch_loop=SimpleNamespace(
+            manual_loop=SimpleNamespace(optim_step_progress=progress))))
 
     def _batches(self, loader: Iterable):
         for i, batch in enumerate(loader):
@@ -86,6 +102,8 @@ class Trainer:
             if val_loader is not None:
                 for i, batch in self._batches(val_loader):
                     model.validation_step(batch, i)
+                if hasattr(model, "validation_epoch_end"):
+                    model.validation_epoch_end(None)
             logs = model.collect_logs()
             logs["epoch"] = epoch
             self.history.append(logs)

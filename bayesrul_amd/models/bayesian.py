@@ -10,8 +10,13 @@ MI355X kernels per batch (`SviEngine.step`).  Differences, all deliberate (DESIG
     (`bnn.predict`, `svi_no_obs.evaluate_loss`, bayesian.py:149-155) come out of the same step:
     predictions of the S training particles and the KL term of the loss;
   * no per-step host synchronisation: logged values stay on the device until the epoch ends;
-  * the variational means are always initialised from `net` (the reference does so only for
-    `pretrain_epochs > 0`; its default `init_to_median` draw is not reproducible, U11).
+  * `pretrain_epochs == 0`: the reference's guides draw the initial means with Pyro's `init_to_median` (the median
+    of 15 prior draws per element, unseeded; guides/radial.py:48, U11).  Here the same statistic is drawn from a
+    generator seeded with `seed`, so a run is reproducible; `pretrain_epochs > 0` starts from `net`'s weights
+    (`PretrainedInitializer.from_net`, bayesian.py:87-91).
+  * the checkpoint's `param_store` entry keeps Pyro's `{"params", "constraints"}` shape with the unconstrained
+    tensors, but the constraint objects are stored by NAME ("real" / "positive"): a real Pyro `set_state` cannot
+    load it.  `import_pyro_param_store` reads a Pyro-written store (site names matched by suffix, U12).
 """
 from __future__ import annotations
 
@@ -74,13 +79,27 @@ class BNN(_Base):
     def __init__(self, net: torch.nn.Module, optimizer, pretrain_epochs: int, mc_samples_train: int,
                  mc_samples_eval: int, dataset_size: int, fit_context: Optional[str], prior_loc: float,
                  prior_scale: float, guide: str, q_scale: float, prec: str = "bf16x3", max_batch: int = 1000,
-                 max_eval_batch: int = 10000, seed: int = 0):
+                 max_eval_batch: int = 10000, seed: int = 0, guide_kwargs: Optional[dict] = None):
         super().__init__()
         self.save_hyperparameters(logger=False, ignore=["net"])
         self.net = net
         self.engine: Optional[SviEngine] = None
 
     # ---- bayesian.py:45-98
+    def _initial_means(self) -> Dict[str, torch.Tensor]:
+        """bayesian.py:87-91 / guides/radial.py:48: the net's weights when pre-trained, else a seeded stand-in for
+        `init_to_median(num_samples=15)`: per element the median of 15 draws of the prior."""
+        hp = self.hparams
+        sd = {k: v.detach() for k, v in copy.deepcopy(self.net).state_dict().items()}
+        if hp.pretrain_epochs > 0:
+            return sd
+        g = torch.Generator().manual_seed(int(hp.seed))
+        out = {}
+        for k, v in sd.items():
+            draws = hp.prior_loc + hp.prior_scale * torch.randn((15,) + tuple(v.shape), generator=g)
+            out[k] = draws.median(0).values   # torch's median of 15 = the 8th order statistic, as Pyro's
+        return out
+
     def define_bnn(self) -> None:
         hp = self.hparams
         if not hp.pretrain_epochs == 0:
@@ -89,6 +108,8 @@ class BNN(_Base):
             raise RuntimeError("Guide unknown. Choose from 'normal', 'radial'.")
         kind = type(self.net).__name__.lower()
         net_kind = "inception" if "inception" in kind else "linear"
+        if getattr(self.net, "activation", "relu") != "relu" or getattr(self.net, "dropout", 0):
+            raise RuntimeError("the MI355X kernels implement the ReLU / no-dropout nets every reference config uses")
         if not hasattr(self.net, "win_length"):
             raise AttributeError("net must carry win_length / n_features (bayesian.py:117-118)")
         S = max(hp.mc_samples_train, hp.mc_samples_eval)
@@ -97,14 +118,18 @@ class BNN(_Base):
         self.engine = SviEngine(net=net_kind, guide=hp.guide, fit_context=hp.fit_context, prec=hp.prec, max_particles=S,
                                 max_batch=max(B, hp.max_eval_batch), win_length=self.net.win_length,
                                 n_features=self.net.n_features, device=self.device, max_windows=eval_windows)
-        mu0 = {k: v.detach() for k, v in copy.deepcopy(self.net).state_dict().items()}
-        self.engine.init_params(mu0, hp.q_scale)
+        self.engine.init_params(self._initial_means(), 1.0)
+        guide_cls = AutoNormal if hp.guide == "normal" else AutoRadial
+        guide = guide_cls(self.engine, **{"init_scale": hp.q_scale, **dict(hp.guide_kwargs or {})})
         if getattr(self, "_pending_param_store", None) is not None:
             self._restore_param_store(self._pending_param_store)
             self._pending_param_store = None
-        guide_cls = AutoNormal if hp.guide == "normal" else AutoRadial
-        self.bnn = VariationalBNN(self.engine, guide_cls(self.engine, init_scale=hp.q_scale))
+        if getattr(self, "_pending_engine_state", None) is not None:   # Adam moments, step count, decayed lr
+            self.engine.load_state_dict(self._pending_engine_state)
+            self._pending_engine_state = None
+        self.bnn = VariationalBNN(self.engine, guide)
         self.adam = _adam_hyper(hp.optimizer)
+        self.adam.train_loc, self.adam.train_scale = guide.train_loc, guide.train_scale
 
     # ---- bayesian.py:100-132
     def on_fit_start(self) -> None:
@@ -114,13 +139,27 @@ class BNN(_Base):
     def _metrics(self, loc, scale, y):
         return F.mse_loss(y, loc), rms_calibration_error(loc, scale, y), sharpness(scale)
 
+    def _optim_step_progress(self):
+        """bayesian.py:144,156: the reference pokes Lightning's manual-optimisation progress tracker so that the
+        trainer counts optimiser steps (checkpointing, `global_step`) although no torch optimiser is registered.
+        Present only under a trainer that has that loop structure (pytorch-lightning 1.9; the lite trainer mirrors it)."""
+        try:
+            return self.trainer.fit_loop.epoch_loop.batch_loop.manual_loop.optim_step_progress
+        except (AttributeError, RuntimeError):
+            return None
+
     # ---- bayesian.py:134-166
     def training_step(self, batch, batch_idx):
         x, y = batch[0].contiguous().float(), batch[1].contiguous().float().reshape(-1)
         hp = self.hparams
         S = hp.mc_samples_train
+        prog = self._optim_step_progress()
+        if prog is not None:
+            prog.increment_ready()
         res, preds = self.engine.step(x, y, S, hp.dataset_size, hp.prior_loc, hp.prior_scale, self.adam,
                                       seed=hp.seed, want_preds=True)
+        if prog is not None:
+            prog.increment_completed()
         elbo, kl = res[0], res[1]
         output = aggregate_predictions(preds) if S > 1 else preds[0]
         loc, scale = output[:, 0], output[:, 1]
@@ -205,9 +244,24 @@ class BNN(_Base):
                 eng.loc(name).copy_(store["params"][f"net_guide.{name}.loc"].to(eng.device))
                 eng.log_scale(name).copy_(store["params"][f"net_guide.{name}.scale"].to(eng.device))
 
+    def import_pyro_param_store(self, store: Dict) -> None:
+        """Best-effort import of a param store written by the reference itself (`pyro.get_param_store().get_state()`,
+        bayesian.py:255-258): its `params` are the unconstrained tensors, named `<prefix><site>.loc / .scale` where
+        the prefix depends on TyXe's module nesting (unverified here, U12) — sites are matched by suffix.  Needs the
+        engine (call after `on_fit_start` / `on_test_start` / `on_predict_start`)."""
+        params = store["params"]
+        with torch.no_grad():
+            for name, _, _ in self.engine.sites:
+                for suffix, view in ((".loc", self.engine.loc), (".scale", self.engine.log_scale)):
+                    hits = [k for k in params if k.endswith(name + suffix)]
+                    if len(hits) != 1:
+                        raise RuntimeError(f"param store: {len(hits)} entries end with '{name + suffix}'")
+                    view(name).copy_(params[hits[0]].to(self.engine.device).reshape(view(name).shape))
+
     def on_load_checkpoint(self, checkpoint: Dict) -> None:
         if self.engine is None:  # restored when define_bnn builds the engine (on_*_start)
             self._pending_param_store = checkpoint["param_store"]
+            self._pending_engine_state = checkpoint.get("svi_engine")
         else:
             self._restore_param_store(checkpoint["param_store"])
             if "svi_engine" in checkpoint:

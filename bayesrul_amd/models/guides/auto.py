@@ -4,6 +4,7 @@ forward`.  They are *views* on the engine's flat (mu, log sigma) buffers; the sa
 arithmetic itself runs in the HIP kernels (csrc/kernels_misc.h: prep_weights_kernel)."""
 from __future__ import annotations
 
+import math
 from typing import Dict, Optional
 
 import torch
@@ -22,17 +23,41 @@ class RadialNormal(td.Normal):
         return self.loc + direction * distance * self.scale
 
 
+def _prior_std(method: str, weight: torch.Tensor) -> float:
+    fan_in = weight[0].numel() if weight.dim() > 1 else weight.numel()
+    fan_out = weight.shape[0] * (weight[0, 0].numel() if weight.dim() > 2 else 1) if weight.dim() > 1 else weight.numel()
+    if method == "radford":
+        return fan_in ** -0.5
+    if method == "xavier":
+        return math.sqrt(2.0 / (fan_in + fan_out))
+    if method == "kaiming":
+        return math.sqrt(1.0 / fan_in)
+    raise RuntimeError(f"unknown init_scale rule {method!r}")
+
+
 class _AutoGuide:
     dist_cls = td.Normal
 
-    def __init__(self, engine, init_scale: float = 1e-1, train_loc: bool = True, train_scale: bool = True,
+    def __init__(self, engine, init_scale=1e-1, train_loc: bool = True, train_scale: bool = True,
                  max_guide_scale: Optional[float] = None):
+        """guides/radial.py:44-95.  `init_scale`: a number, a dict {site: tensor} or the name of a fan-based rule
+        ("radford" | "xavier" | "kaiming", `tyxe.util.calculate_prior_std` [3P, from memory]); it sets rho = log(scale).
+        `train_loc / train_scale = False` freeze the parameter in the fused optimiser.  `max_guide_scale` (an interval
+        constraint on the scale, i.e. another unconstrained parametrisation) is not implemented by the kernels."""
         if max_guide_scale is not None:
-            raise RuntimeError("max_guide_scale (interval constraint) is not used by any reference config")
-        if not (train_loc and train_scale):
-            raise RuntimeError("train_loc / train_scale = False are not used by any reference config")
+            raise RuntimeError("max_guide_scale (interval-constrained scale) is not implemented by the MI355X kernels; "
+                               "no reference config uses it")
         self.engine = engine
-        self.init_scale = init_scale
+        self.init_scale, self.train_loc, self.train_scale = init_scale, bool(train_loc), bool(train_scale)
+        with torch.no_grad():
+            for name, _, _ in engine.sites:
+                rho = engine.log_scale(name)
+                if isinstance(init_scale, dict):
+                    rho.copy_(torch.as_tensor(init_scale[name]).to(rho.device, rho.dtype).log().expand_as(rho))
+                elif isinstance(init_scale, str):
+                    rho.fill_(math.log(_prior_std(init_scale, engine.loc(name))))
+                else:
+                    rho.fill_(math.log(float(init_scale)))
 
     def site_names(self):
         return [s for s, _, _ in self.engine.sites]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BNN_ABI_VERSION 1
+#define BNN_ABI_VERSION 2
 
 enum {
   BNN_OK = 0,
@@ -100,6 +100,10 @@ typedef struct BnnAdamArgs {
   double lr, beta1, beta2, eps, clip_norm, weight_decay;
   int64_t step;            /* 1-based step count after increment */
   double grad_scale;       /* multiplies grad before the clamp (1/world_size after a sum all-reduce) */
+  int32_t freeze_loc;      /* != 0: mu is not updated (guide option train_loc=False, guides/radial.py:74-76) */
+  int32_t freeze_scale;    /* != 0: rho is not updated (train_scale=False, :90-94; the frequentist siblings) */
+  int32_t torch_eps;       /* != 0: torch.optim.Adam's epsilon placement, sqrt(v / bc2) + eps (frequentist siblings) */
+  int32_t reserved;
 } BnnAdamArgs;
 
 /* scalars + predictions produced by a step; device pointers into caller memory */
@@ -114,7 +118,7 @@ typedef struct BnnElboOut {
 int bnn_version(void);
 const char* bnn_last_error(void);
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
- * 0 BnnPlanDesc, 1 BnnBuffers, 2 BnnNoise, 3 BnnElboArgs, 4 BnnAdamArgs, 5 BnnElboOut */
+ * 0 BnnPlanDesc, 1 BnnBuffers, 2 BnnNoise, 3 BnnElboArgs, 4 BnnAdamArgs, 5 BnnElboOut, 6 BnnDetArgs */
 size_t bnn_abi_sizeof(int which);
 
 /* ---- plan: replaces BNN.define_bnn / on_fit_start bookkeeping (bayesian.py:45-132) ---- */
@@ -167,6 +171,20 @@ int bnn_elbo_step(BnnPlan* plan, const BnnElboArgs* a, const BnnNoise* noise, co
 int bnn_elbo_evaluate(BnnPlan* plan, const BnnElboArgs* a, const BnnNoise* noise, const BnnElboOut* out,
                       void* stream);
 
+/* SURVEY.md 8(f) rank 4, the frequentist siblings on the same kernels: one deterministic training step of the net
+ * with weights = mu (no sampling, no KL): forward -> loss -> backward -> d loss / d mu in grad[0..P) [-> optimiser].
+ *   objective 1: HNN.step (bayesrul/models/frequentist.py:39-48): mean_b F.gaussian_nll_loss(loc, y, scale^2)
+ *                (eps = 1e-6, var clamped without gradient), scale = the net's second output (single softplus)
+ *   objective 2: NN.step (:173-178): mean_b (loc - y)^2
+ * out->loss receives the mean loss; out->preds [1][B][2] the net outputs.  adam == NULL leaves the gradient in place. */
+typedef struct BnnDetArgs {
+  const float* x;          /* [B][W][F] */
+  const float* y;          /* [B] */
+  int32_t batch;
+  int32_t objective;       /* 1 gaussian NLL (HNN), 2 MSE (NN) */
+} BnnDetArgs;
+int bnn_det_step(BnnPlan* plan, const BnnDetArgs* a, const BnnAdamArgs* adam, const BnnElboOut* out, void* stream);
+
 /* A16: bnn.predict(x, num_predictions=S, aggregate=False) + the aggregation of
  * predict_step / test_step (bayesian.py:203-250): out4 = [4][B] (preds, stds, ep_vars, al_vars);
  * preds_sb2 (optional) = [S][B][2] raw net outputs. */
@@ -183,9 +201,12 @@ int bnn_export_noise(BnnPlan* plan, const BnnElboArgs* a, uint64_t seed, uint64_
  * Replaces LmdbDataset.__getitem__ (bayesrul/data/lmdb_utils.py:184-194), NCMAPSSLmdbDataset.__getitem__
  * (bayesrul/data/ncmapss/dataset.py:13-16) and the DataLoader collate: x_out[i] = window idx[i], y_out[i] = its RUL.
  * feature_major != 0: stored windows are the reference's LMDB values, [n_features][win_length] fp32, and are
- * transposed to [win_length][n_features] (lmdb_utils.py:190-191).  y_all / y_out may be NULL.  Device pointers. */
-int bnn_gather_windows(const float* x_all, const float* y_all, const int64_t* idx, int64_t n, int32_t win_length,
-                       int32_t n_features, int32_t feature_major, float* x_out, float* y_out, void* stream);
+ * transposed to [win_length][n_features] (lmdb_utils.py:190-191).  y_all / y_out may be NULL.  Device pointers.
+ * n_windows = number of windows stored in x_all: an index outside [0, n_windows) is never dereferenced (the output
+ * window is filled with NaN and the label with NaN, so a bad index is visible, not a fault). */
+int bnn_gather_windows(const float* x_all, const float* y_all, const int64_t* idx, int64_t n, int64_t n_windows,
+                       int32_t win_length, int32_t n_features, int32_t feature_major, float* x_out, float* y_out,
+                       void* stream);
 
 /* ---- measurement: per-kernel durations from HIP events recorded on the launch stream ----
  * tag = kind * 16 + group; kind: 0 group forward, 1 group dX, 2 group dW, 3 weight sampling,
