@@ -23,7 +23,7 @@ EXPORTS = [
     "bnn_plan_bind", "bnn_plan_site", "bnn_plan_layer", "bnn_plan_tensor", "bnn_sample_weights",
     "bnn_forward", "bnn_head_nll", "bnn_backward", "bnn_grad_finalize", "bnn_clipped_adam",
     "bnn_elbo_step", "bnn_elbo_evaluate", "bnn_predict", "bnn_export_noise", "bnn_profile_enable",
-    "bnn_profile_select", "bnn_profile_name", "bnn_profile_read", "bnn_gather_windows", "bnn_det_step",
+    "bnn_profile_select", "bnn_profile_name", "bnn_profile_read", "bnn_gather_windows", "bnn_det_step", "bnn_plan_validate",
 ]
 
 

@@ -497,6 +497,45 @@ __global__ void grad_finalize_kernel(const FinalizeArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Sum of the partial gradient images ("slabs") the fused trunk dW kernels write, one per workgroup, into the
+// per-particle images grad_finalize_kernel reads.  Layer group g (0: layers 0-3, 1: layers 4, 5, 7, 9, 2: layers 6, 8)
+// owns n[g] slabs per particle; a slab has the forward image layout of the conv layers (stride floats).  Fixed summation
+// order: bitwise reproducible.  One thread per (particle, image element); eight independent partial sums keep eight
+// loads in flight.
+// ------------------------------------------------------------------------------------------
+struct SlabReduceArgs {
+  const float* slab[3];     // [S * n[g]][stride]
+  int n[3];
+  long stride;              // floats per slab
+  long lay_end[10];         // end offset of conv layer l inside a slab (images are in layer order)
+  float* out;               // [S][out_stride]
+  long out_stride;
+  long elems;               // elements to reduce (= lay_end[9])
+  int S;
+};
+
+__global__ void slab_reduce_kernel(const SlabReduceArgs A) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.y;
+  if (e >= A.elems) return;
+  int layer = 0;
+#pragma unroll
+  for (int l = 0; l < 9; ++l)
+    if (e >= A.lay_end[l]) layer = l + 1;
+  const int g = layer < 4 ? 0 : ((layer == 6 || layer == 8) ? 2 : 1);
+  const int n = A.n[g];
+  const float* p = A.slab[g] + (long)s * n * A.stride + e;
+  float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] += p[(long)(k + u) * A.stride];
+  }
+  for (; k < n; ++k) t[0] += p[(long)k * A.stride];
+  A.out[(long)s * A.out_stride + e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+}
+
+// ------------------------------------------------------------------------------------------
 // ClippedAdam on the flat (mu, rho) buffer  (A12)
 // ------------------------------------------------------------------------------------------
 struct AdamArgs {

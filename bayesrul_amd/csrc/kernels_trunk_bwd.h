@@ -250,7 +250,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
     lds_barrier();
     for (int t = 0; t < nsteps; ++t) {
       const int k = t;
-      if (k < nwin) {
+      if (k < nwin && !(TX_ABL & 64)) {
         const char* sl = smem + TX_O_SLOT + (k % 3) * TX_SLOT;
         const uint32_t* sg = (const uint32_t*)(smem + TX_O_SGN) + (k % 3) * 80;
         const unsigned R0 = (unsigned)(Rs + k * Rstep);
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
           }
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < ((TX_ABL & 16) ? 0 : 2); ++mt) {
 #pragma unroll
           for (int qb = 0; qb < 6; qb += 3) {   // three k-steps per batch: 6 fragments in flight
             __builtin_amdgcn_sched_barrier(0);
@@ -406,6 +406,9 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
             }
           }
         }
+        if constexpr (TX_ABL & 32) {
+          asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(accp[0]), "v"(accp[1]));
+        } else {
         // pooled branch: this row's gradient goes to row + code - 1 (codes of the forward's MaxPool1d(3,1,1))
         f32x4 v[2], up[2], dn[2];
 #pragma unroll
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
             if constexpr (!(TX_ABL & 1)) *(uint2*)((char*)A.g_act1 + ((R0 + (unsigned)row) * 256u + (unsigned)(och * 2))) = d;
             else asm volatile("" ::"v"(d.x), "v"(d.y));
           }
+        }
         }
       }
       lds_barrier();

@@ -6,7 +6,9 @@
 //   128-channel image : byte(row, chunk16) = 256 row + 16 (chunk16 ^ f(row)),  f = ((row & 3) << 2) | ((row >> 2) & 3)
 //   32-channel image  : byte(row, chunk16) =  64 row + 16 (chunk16 ^ ((row >> 2) & 3))
 // A workgroup owns a particle and a strided set of its windows; tiles stay in registers across the windows and are
-// added to the per-particle fp32 gradient images with atomics at the end.  Flipout's second product
+// written ONCE, with plain stores, into the workgroup's own partial image ("slab", forward image layout); the chain
+// rule kernel sums the slabs of a particle (grad_finalize_kernel).  No atomics: the sums are bitwise reproducible, and
+// plain stores run at ~4x the chip-wide float-atomic rate (MI355X_MICROARCH.md, Global float atomics).  Flipout's second product
 // (dz o s_out)^T (x o s_in) flips the sign bit of the transposed fragments per lane (a channel per lane).
 // Two loader waves alternate windows (global -> registers -> LDS, two steps ahead); one barrier per window.
 #pragma once
@@ -31,7 +33,7 @@ struct TrunkDw1Args {
   const uint32_t* sign_in;
   const uint32_t* sign_out;
   long examples;
-  float* gw_a; float* gw_b; float* gb_a;
+  float* gw_a; float* gw_b; float* gb_a;   // slabs of this kernel: [S * nsplit][gw_stride] / [S * nsplit][gb_stride]
   long gw_stride; int gb_stride;
   int S, B, L, nsplit;
 };
@@ -109,8 +111,8 @@ struct Dw1Job {
           const int n = NT * 16 + i4 + r;
           if (n >= ly.cout) continue;
           const long o = (long)n * ly.KP + (long)t * ly.cin_img + ch;
-          atomicAdd(gwa + o, acc_a[t][c][r]);
-          if constexpr (FO) atomicAdd(gwb + o, acc_b[t][c][r]);
+          gwa[o] = acc_a[t][c][r];
+          if constexpr (FO) gwb[o] = acc_b[t][c][r];
         }
       }
     if constexpr (BIAS) {
@@ -118,7 +120,7 @@ struct Dw1Job {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = NT * 16 + i4 + r;
-          if (n < ly.cout) atomicAdd(A.gb_a + (long)A.gb_stride * s + ly.bias_off + n, acc_bias[r]);
+          if (n < ly.cout) A.gb_a[(long)A.gb_stride * s + ly.bias_off + n] = acc_bias[r];
         }
       }
     }
@@ -143,8 +145,8 @@ __device__ __forceinline__ void dw1_role(const TrunkDw1Args& A, char* smem, int 
     j1.run(sl, sg, lane, ones);
     lds_barrier();
   }
-  j0.flush(A, s, lane);
-  j1.flush(A, s, lane);
+  j0.flush(A, (int)blockIdx.x, lane);   // slab = this workgroup's (particle, split)
+  j1.flush(A, (int)blockIdx.x, lane);
 }
 
 template <int EM>
@@ -281,7 +283,7 @@ struct TrunkDw2Args {
   const uint32_t* sign_in;
   const uint32_t* sign_out;
   long examples;
-  float* gw_a; float* gw_b; float* gb_a;
+  float* gw_a; float* gw_b; float* gb_a;   // slabs of this kernel: [S * nsplit][gw_stride] / [S * nsplit][gb_stride]
   long gw_stride; int gb_stride;
   int S, B, L, nsplit;
 };
@@ -364,8 +366,8 @@ struct Dw2Job {
           const int n = NT * 16 + i4 + r;
           if (n >= ly.cout) continue;
           const long o = (long)n * ly.KP + (long)t * ly.cin_img + ch;
-          atomicAdd(gwa + o, acc_a[t][c][r]);
-          if constexpr (FO) atomicAdd(gwb + o, acc_b[t][c][r]);
+          gwa[o] = acc_a[t][c][r];
+          if constexpr (FO) gwb[o] = acc_b[t][c][r];
         }
       }
     if constexpr (BIAS) {
@@ -373,7 +375,7 @@ struct Dw2Job {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int n = NT * 16 + i4 + r;
-          if (n < ly.cout) atomicAdd(A.gb_a + (long)A.gb_stride * s + ly.bias_off + n, acc_bias[r]);
+          if (n < ly.cout) A.gb_a[(long)A.gb_stride * s + ly.bias_off + n] = acc_bias[r];
         }
       }
     }
@@ -398,8 +400,8 @@ __device__ __forceinline__ void dw2_role(const TrunkDw2Args& A, char* smem, int 
     j1.run(sl, sg, lane, ones);
     lds_barrier();
   }
-  j0.flush(A, s, lane);
-  j1.flush(A, s, lane);
+  j0.flush(A, (int)blockIdx.x, lane);   // slab = this workgroup's (particle, split)
+  j1.flush(A, (int)blockIdx.x, lane);
 }
 
 struct Dw2Empty {

@@ -44,6 +44,10 @@ static int fail(int code, const char* fmt, ...) {
     if (rc__ != 0) return rc__; \
   } while (0)
 
+// bnn_plan_validate: the launch functions run their geometry checks and return before touching the device
+static thread_local bool g_dry = false;
+#define BNN_DRY_RETURN() do { if (g_dry) return 0; } while (0)
+
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 static inline long rupl(long v, long m) { return (v + m - 1) / m * m; }
 
@@ -108,16 +112,10 @@ struct ProfScope {
 };
 enum { PK_FWD = 0, PK_DX = 1, PK_DW = 2, PK_SAMPLE = 3, PK_HEAD = 4, PK_FINALIZE = 5, PK_ADAM = 6, PK_POOLBWD = 7, PK_NOISE = 8 };
 
-enum { DBG_STAMP_BYTES = 16 * 48 * 8 * 8 };
-struct BnnPlan;
-static unsigned long long* dbg_for(const BnnPlan* p, int kind, int gi);
 
 struct BnnPlan {
   BnnPlanDesc d;
   Prof prof;
-  unsigned long long* dbg_buf = nullptr;   // diagnostics only (bnn_debug_stamps): device stamp buffer
-  int dbg_tag = -1;                        // kind * 16 + group of the launch that records stamps
-  int dbg_block = 0;                       // workgroup that records
   int n_layers = 0, n_sites = 0, n_groups = 0;
   long P = 0;
   std::vector<std::string> site_names, layer_names;
@@ -133,6 +131,9 @@ struct BnnPlan {
   int x_ctot = 18;
   // workspace layout (byte offsets)
   size_t ws_bytes = 0;
+  size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
+  long slab_stride = 0;
+  int slab_bstride = 0;
   size_t o_layers, o_a_hi, o_a_lo, o_b, o_at, o_bt, o_bias_a, o_bias_b, o_gw_a, o_gw_b, o_gb_a, o_gb_b, o_eps, o_radr,
       o_norms, o_sign_in, o_sign_out, o_acc, o_scal, o_preds, o_poolgrad, o_xplanes, o_amax, o_tens;
   size_t elem = 4;
@@ -387,6 +388,18 @@ static void layout_workspace(BnnPlan* p) {
   p->o_preds = take((size_t)S * p->d.max_batch * 2 * 4);
   p->o_poolgrad = take((size_t)cap * p->d.win_length * 128 * 4);
   p->o_amax = take(p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION ? (size_t)cap * p->d.win_length * 128 : 0);
+  // fused trunk dW: one partial image per workgroup, S * nsplit <= 256 (512 for the k3 / k5 kernel) whatever the call
+  p->slab_stride = 0;
+  if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
+    p->slab_stride = rupl(p->layers[10].w_off, 64);
+    p->slab_bstride = rup(p->layers[10].bias_off, 16);
+    const int slots[3] = {256, 256, 512};
+    for (int g = 0; g < 3; ++g) {
+      p->o_slab_a[g] = take((size_t)slots[g] * p->slab_stride * 4);
+      p->o_slab_b[g] = take((size_t)slots[g] * p->slab_stride * 4);
+      p->o_slab_ba[g] = take((size_t)slots[g] * p->slab_bstride * 4);
+    }
+  }
   p->o_xplanes = take((size_t)4 * p->d.max_batch * p->d.win_length * 32 * 2);   // x hi | lo | pooled hi | pooled lo
   p->o_tens = o;
   // activations / grads / q.  f32 plans keep fp32 rows; bf16x3 plans keep bf16 planes
@@ -460,7 +473,8 @@ extern "C" int bnn_plan_create(const BnnPlanDesc* desc, BnnPlan** out) {
   return 0;
 }
 extern "C" void bnn_plan_destroy(BnnPlan* plan) {
-  if (plan && plan->dbg_buf) (void)hipFree(plan->dbg_buf);
+  if (plan)
+    for (hipEvent_t e : plan->prof.ev) (void)hipEventDestroy(e);
   delete plan;
 }
 extern "C" int bnn_plan_num_params(const BnnPlan* p, int64_t* P) {
@@ -759,7 +773,6 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
   }
   A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), nullptr, 128, p->d.prec == BNN_PREC_BF16X3 ? TF_BF16 : TF_F32};
   A->amax = nullptr;
-  A->dbg_block = p->dbg_block;
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION && c->train)   // no backward, no codes (evaluate / predict)
     for (int b = 0; b < A->g.n_branch; ++b)
       if (A->g.br[b].pool && A->g.br[b].dx_t >= 0) A->amax = (unsigned char*)w + p->o_amax;
@@ -770,10 +783,6 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
   A->gb_b = ws_f(p, p->o_gb_b);
   A->gw_stride = p->img_total;
   A->gb_stride = p->bias_total;
-}
-
-static unsigned long long* dbg_for(const BnnPlan* p, int kind, int gi) {
-  return (p->dbg_buf && p->dbg_tag == kind * 16 + gi) ? p->dbg_buf : nullptr;
 }
 
 static int img_bytes(int ch, bool bf) { return (IMG_ROWS * img_row_stride(ch, bf) * (bf ? 2 : 4) + 15) & ~15; }
@@ -787,6 +796,7 @@ static int launch_fwd(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int
   A.lds_per_wave = nimg * img_bytes(DENSE_CHUNK, P::BF);
   const int lds = 4 * A.lds_per_wave;
   const unsigned grid = (unsigned)std::min((A.cg.nwin * A.g.n_branch + 3) / 4, 2048);   // items = (window, branch)
+  BNN_DRY_RETURN();
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(group_fwd_kernel<P, EM_PLAIN>, lds));
     group_fwd_kernel<P, EM_PLAIN><<<dim3(grid), dim3(256), lds, st>>>(A);
@@ -810,6 +820,7 @@ static int launch_dx(const GroupArgs& A0, int em, int pool_sel, hipStream_t st, 
   A.lds_per_wave = 2 * img_bytes(DENSE_CHUNK, P::BF);
   const int lds = 4 * A.lds_per_wave;
   const unsigned grid = (unsigned)std::min((A.cg.nwin + 3) / 4, 2048);
+  BNN_DRY_RETURN();
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(group_dx_kernel<P, EM_PLAIN>, lds));
     group_dx_kernel<P, EM_PLAIN><<<dim3(grid), dim3(256), lds, st>>>(A);
@@ -838,6 +849,7 @@ static int launch_dw(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int 
   nsplit = std::min(nsplit, max_split);
   A.nsplit = nsplit;
   const unsigned grid = (unsigned)(njobs * A.cg.S * nsplit);
+  BNN_DRY_RETURN();
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(group_dw_kernel<P, EM_PLAIN, NW>, lds));
     group_dw_kernel<P, EM_PLAIN, NW><<<dim3(grid), dim3(NW * 64), lds, st>>>(A);
@@ -880,8 +892,8 @@ static int build_conv_fwd2_jobs(const GroupArgs& A, const LayerDesc* layers, uns
   bool any_split = false;
   for (const Tile& t : tiles) any_split |= t.nm > 1;
   // keep splitting the longest job while it has more than 2 k-steps (measured optimum on the block-2 k3/k5 group:
-  // finer splits cost more in the LDS reduction than they save in MFMAs); BNN_FWD_FILL overrides for experiments
-  const double fill_thr = getenv("BNN_FWD_FILL") ? atof(getenv("BNN_FWD_FILL")) : 2.0;
+  // finer splits cost more in the LDS reduction than they save in MFMAs)
+  const double fill_thr = 2.0;
   while (any_split && njobs < nc) {
     int best = -1;
     double bv = fill_thr;
@@ -915,6 +927,7 @@ static int build_conv_fwd2_jobs(const GroupArgs& A, const LayerDesc* layers, uns
 
 template <int NC, int NL>
 static int launch_conv_fwd_dma_t(const GroupArgs& A, const ConvFwd2Plan& F, int em, int lds, unsigned grid, hipStream_t st) {
+  BNN_DRY_RETURN();
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_PLAIN, NC, NL>, lds));
     conv_fwd_dma_kernel<EM_PLAIN, NC, NL><<<dim3(grid), dim3((NC + NL) * 64), lds, st>>>(A, F);
@@ -932,13 +945,20 @@ static int launch_conv_fwd_dma_t(const GroupArgs& A, const ConvFwd2Plan& F, int 
 static int launch_conv_fwd_dma(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   ConvFwd2Plan F{};
-  if (const char* dbg = getenv("BNN_FWD_ABLATE")) A.pool_sel = atoi(dbg);  // timing experiments only (wrong results)
   const int c8n = A.g.in_cin_p / 8;
   if (c8n != 4 && c8n != 16) return fail(BNN_E_INVALID, "conv fwd: input of %d channels (need 32 or 128)", A.g.in_cin_p);
   if ((A.g.L * c8n + 63) / 64 * 2 > 16) return fail(BNN_E_INVALID, "conv fwd: window too large for the loader plan");
   const int pbytes = IMG_ROWS * A.g.in_cin_p * 2;
+  {
+    // LDS-DMA geometry of a plane: ninst instructions of 64 lanes x 16 B land at rows [HALO, HALO + L); the counted
+    // vmcnt of a loader (its share of 2 planes x ninst, + the sign word) must stay inside the wait macro's range
+    const int nchunk = A.g.L * c8n, ninst = (nchunk + 63) / 64;
+    if (HALO * A.g.in_cin_p * 2 + nchunk * 16 > pbytes) return fail(BNN_E_INVALID, "conv fwd: a window overruns its LDS plane");
+    if ((2 * ninst + 1) / 2 + 1 > 12) return fail(BNN_E_INVALID, "conv fwd: %d DMA instructions per loader exceed the counted-wait range", ninst);
+    static_assert(FW_SLOTS >= 2 + 1, "two windows in flight need three slots");
+  }
   // preferred: two workgroup kinds of 8 waves (6 compute + 2 loaders), two workgroups per CU
-  bool two = A.g.n_branch > 1 && !getenv("BNN_FWD_ONEKIND");
+  bool two = A.g.n_branch > 1;
   if (two) {
     // deal the branches: heaviest (k-steps x n-tiles) first onto the lighter kind
     int wgt[BNN_MAX_BRANCH], order[BNN_MAX_BRANCH], load[2] = {0, 0};
@@ -1003,6 +1023,7 @@ static void build_conv_dw_plan(const GroupArgs& A, const LayerDesc* layers, Conv
 
 template <int EM, int NWI>
 static int launch_conv_dw_mw_em(const GroupArgs& A, const ConvDwPlan& D, int lds, unsigned grid, int nwv, hipStream_t st) {
+  BNN_DRY_RETURN();
   const int tpw = (D.ntiles + nwv - 1) / nwv;
   if (nwv == 16) {   // 16-wave workgroups: at most 6 tiles per wave, one window per iteration
     if constexpr (NWI == 1) {
@@ -1029,7 +1050,6 @@ static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int e
   GroupArgs A = A0;
   ConvDwPlan D;
   build_conv_dw_plan(A, layers, &D);
-  if (const char* dbg = getenv("BNN_DW_ABLATE")) A.pool_sel = atoi(dbg);  // timing experiments only
   if (D.ntiles > 96 || (D.ntiles + CV_WAVES - 1) / CV_WAVES > 11) return fail(BNN_E_INVALID, "conv dW plan too large");
   if (A.g.in_cin_p % 8 || D.zw % 8) return fail(BNN_E_INVALID, "conv dW: channel counts must be multiples of 8");
   if (A.g.L * (A.g.in_cin_p / 8) > CV_THREADS || A.g.L * (D.zw / 8) > 2 * CV_THREADS)
@@ -1048,10 +1068,9 @@ static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int e
   // window's loads in flight
   // (plain contraction only: the Flipout / LRT variants of that shape need more than the 128 registers of a
   // 16-wave workgroup)
-  int nwv = (tpw > 6 && em == EM_PLAIN && !getenv("BNN_DW_8WAVES")) ? 16 : 8;
+  int nwv = (tpw > 6 && em == EM_PLAIN) ? 16 : 8;
   if (nwv == 16) tpw = (D.ntiles + 15) / 16;
   int nwi = lrt ? (tpw > 6 ? 1 : 2) : (nwv == 16 || tpw > 6 ? 1 : (em == EM_FLIPOUT ? 2 : 4));
-  if (const char* e = getenv("BNN_DW_NWI")) nwi = nwv == 16 ? 1 : atoi(e);   // experiments only (1, 2 or 4)
   while (nwi > 1 && nwi * wbytes > 160 * 1024) nwi /= 2;
   if (nwi * wbytes > 160 * 1024) return fail(BNN_E_INVALID, "conv dW: %d bytes of LDS per window", wbytes);
   const int lds = nwi * wbytes;
@@ -1077,6 +1096,7 @@ static int launch_dense_dw_bf(const GroupArgs& A0, int em, hipStream_t st, Prof*
   const unsigned grid = (unsigned)(A.cg.S * nchunk * nsplit);
   ProfScope ps_(pf, PK_DW, gi, st);
   ps_.name("dense_dw_bf_kernel<%d>", em);
+  BNN_DRY_RETURN();
   if (em == EM_PLAIN) dense_dw_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
   else if (em == EM_LRT) dense_dw_bf_kernel<EM_LRT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
   else dense_dw_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
@@ -1092,8 +1112,8 @@ static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em,
   const int L = A.g.L, xw = A.g.in_cin_p;
   const int npt = em == EM_LRT ? 3 : 2;
   D.ntile = xw / 16;
-  // 8 tiles: one 10-wave workgroup kind (every slice loaded and masked once) unless BNN_DX_NC4 asks for two 6-wave kinds
-  const int nc = (D.ntile > 4 && !getenv("BNN_DX_NC4")) ? 8 : 4;
+  // 8 tiles: one 10-wave workgroup kind (every slice loaded and masked once); narrow tensors: 6-wave kinds
+  const int nc = D.ntile > 4 ? 8 : 4;
   const int nw = nc + DX2_NL;
   D.nkinds = (D.ntile + nc - 1) / nc;
   int zel = 0, units = 0;
@@ -1170,6 +1190,11 @@ static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em,
   if (D.has_pool)
     BNN_TRY(add_stream(A.amax, (uint32_t)L * xw, (uint32_t)xw, xw / 16, 0, (uint32_t)(D.o_am + HALO * xw)));
   D.ninst = ni;
+  for (int i = 0; i < ni; ++i) {   // every DMA instruction lands inside the slot
+    const Dx2Inst& I = D.inst[i];
+    const uint32_t q0 = I.geom & 0xffffu, lanes = std::min<uint32_t>(64u, I.qn - q0);
+    if (I.dst + lanes * 16u > (uint32_t)D.slot_bytes) return fail(BNN_E_INVALID, "conv dX: DMA instruction %d overruns its slot", i);
+  }
   if ((ni + DX2_NL - 1) / DX2_NL + 1 > 49) return fail(BNN_E_INVALID, "conv dX: %d DMA instructions per window", ni);
   // slots: 3 (two windows ahead) if two workgroups still share a CU, else 2 if that makes them fit
   const int extra = 4096;
@@ -1185,6 +1210,8 @@ static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em,
     D.nslots = total(3) <= 160 * 1024 ? 3 : 2;
   }
   const int lds = total(D.nslots);
+  if (D.nslots < 2 || (D.nslots - 2) * ((ni + DX2_NL - 1) / DX2_NL + 1) > 49)
+    return fail(BNN_E_INVALID, "conv dX: %d slots / %d DMA instructions exceed the counted-wait range", D.nslots, ni);
   if (lds > 160 * 1024) return fail(BNN_E_INVALID, "conv dX: %d bytes of LDS", lds);
   D.nsplit = std::max(1, std::min(A.cg.B, (256 * wg_per_cu) / std::max(1, A.cg.S * D.nkinds)));
   const unsigned grid = (unsigned)(A.cg.S * D.nsplit * D.nkinds);
@@ -1200,6 +1227,7 @@ static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em,
       conv_dx2_kernel<EMV, 5, KPV, 4><<<dim3(grid), dim3(nw * 64), lds, st>>>(A, D);           \
     }                                                                                          \
   } while (0)
+  BNN_DRY_RETURN();
   if (em == EM_PLAIN) {
     if (nkp) LAUNCH_DX2(EM_PLAIN, 1); else LAUNCH_DX2(EM_PLAIN, 0);
   } else if (em == EM_LRT) {
@@ -1229,10 +1257,13 @@ static int launch_dense_fwd2(const GroupArgs& A0, int em, hipStream_t st, Prof* 
   F.nchunk = (br.cin_p + DF_CH - 1) / DF_CH;
   if (F.ntile > DF_NC) return fail(BNN_E_INVALID, "dense fwd: %d n-tiles", F.ntile);
   const int slot_bytes = 2 * DF_ROWS * DF_CH * 2 + DF_ROWS * 4 * 4;
+  static_assert(DF_ROWS * DF_CH * 2 == 8 * 1024, "a chunk plane is exactly the 8 DMA instructions a loader issues for it");
+  static_assert((DF_SLOTS - 2) * 9 <= 49 && DF_SLOTS >= 3, "chunks in flight: counted-wait range / slot ring");
   const int lds = DF_SLOTS * slot_bytes + (em == EM_LRT ? DF_ROWS * DF_CH * 2 : 0) + (em == EM_FLIPOUT ? 4096 : 0);
   const unsigned grid = (unsigned)(((A.cg.nwin + 7) / 8) * 8);   // XCD-aware window order inside the kernel
   ProfScope ps_(pf, PK_FWD, gi, st);
   ps_.name("dense_fwd2_kernel<%d>", em);
+  BNN_DRY_RETURN();
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(dense_fwd2_kernel<EM_PLAIN>, lds));
     dense_fwd2_kernel<EM_PLAIN><<<dim3(grid), dim3(DF_NW * 64), lds, st>>>(A, F);
@@ -1254,6 +1285,7 @@ static int launch_dense_dx_bf(const GroupArgs& A0, int em, hipStream_t st, Prof*
   const unsigned grid = (unsigned)A.cg.nwin;
   ProfScope ps_(pf, PK_DX, gi, st);
   ps_.name("dense_dx_bf_kernel<%d>", em);
+  BNN_DRY_RETURN();
   if (em == EM_PLAIN) dense_dx_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(DDX_WAVES * 64), lds, st>>>(A);
   else if (em == EM_LRT) dense_dx_bf_kernel<EM_LRT><<<dim3(grid), dim3(DDX_WAVES * 64), lds, st>>>(A);
   else dense_dx_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DDX_WAVES * 64), lds, st>>>(A);
@@ -1271,9 +1303,11 @@ static int launch_trunk_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, cons
   const long rows = (long)c->B * L;
   const size_t plane = (size_t)p->d.max_batch * L * 32;
   u16* xp = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
-  x_planes4_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xp, xp + plane, xp + 2 * plane,
-                                                                                      xp + 3 * plane, rows, L, p->d.n_features);
-  HIP_TRY(hipGetLastError());
+  if (!g_dry) {
+    x_planes4_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xp, xp + plane, xp + 2 * plane,
+                                                                                        xp + 3 * plane, rows, L, p->d.n_features);
+    HIP_TRY(hipGetLastError());
+  }
   GroupArgs G;
   fill_group_args(p, a, c, 0, x, &G);
   TrunkArgs T{};
@@ -1293,6 +1327,9 @@ static int launch_trunk_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, cons
   T.B = c->B;
   T.L = L;
   T.nsplit = std::max(1, std::min(c->B, 256 / std::max(1, c->S)));
+  static_assert(TR_LDS <= 160 * 1024 && TX_LDS <= 160 * 1024 && TW2A_LDS <= 160 * 1024 && 2 * TW2B_LDS <= 160 * 1024, "LDS budgets");
+  static_assert(2 * (2 * ((30 * 16 + 63) / 64) + (30 * 8 + 63) / 64) <= 49, "trunk dX: DMA instructions of two steps within the counted-wait range");
+  if (L > 30 || L < 1 || p->d.n_features != 18) return fail(BNN_E_INVALID, "trunk kernels: windows of 1..30 rows x 18 features");
   if ((long)c->S * c->B * L * 256 >= (1L << 32))
     return fail(BNN_E_INVALID, "trunk kernels address rows with 32-bit byte offsets: S*B*L = %ld rows exceed 2^24", (long)c->S * c->B * L);
   const unsigned grid = (unsigned)(c->S * T.nsplit);
@@ -1303,6 +1340,7 @@ static int launch_trunk_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, cons
     BNN_TRY(set_lds(trunk_fwd_kernel<EMV, TRV>, TR_LDS));                                       \
     trunk_fwd_kernel<EMV, TRV><<<dim3(grid), dim3(TR_THREADS), TR_LDS, c->st>>>(T);             \
   } while (0)
+  BNN_DRY_RETURN();
   if (c->em == EM_FLIPOUT) {
     if (c->train) LAUNCH_TRUNK(EM_FLIPOUT, true); else LAUNCH_TRUNK(EM_FLIPOUT, false);
   } else {
@@ -1312,6 +1350,10 @@ static int launch_trunk_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, cons
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// workgroups per particle of the trunk dW kernels (group 0: block 1, 1: block 2's 1x1 level, 2: its k3 / k5 level: small
+// workgroups, two per CU); S * nsplit slabs are written and summed by grad_finalize_kernel
+static int trunk_dw_nsplit(const Ctx* c, int g) { return std::max(1, std::min(c->B, (g == 2 ? 512 : 256) / std::max(1, c->S))); }
 
 // dW of block 1 (kernels_trunk_dw.h): transposed-read tiles in registers across a particle's windows
 static int launch_trunk_dw1(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
@@ -1327,13 +1369,14 @@ static int launch_trunk_dw1(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   T.sign_in = c->nz.sign_in;
   T.sign_out = c->nz.sign_out;
   T.examples = (long)c->S * c->B;
-  T.gw_a = G.gw_a; T.gw_b = G.gw_b; T.gb_a = G.gb_a;
-  T.gw_stride = G.gw_stride; T.gb_stride = G.gb_stride;
+  T.gw_a = ws_f(p, p->o_slab_a[0]); T.gw_b = ws_f(p, p->o_slab_b[0]); T.gb_a = ws_f(p, p->o_slab_ba[0]);
+  T.gw_stride = p->slab_stride; T.gb_stride = p->slab_bstride;
   T.S = c->S; T.B = c->B; T.L = p->d.win_length;
-  T.nsplit = std::max(1, std::min(c->B, 256 / std::max(1, c->S)));
+  T.nsplit = trunk_dw_nsplit(c, 0);
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DW, 0, c->st);
   ps_.name("trunk_dw1_kernel<%d>", c->em);
+  BNN_DRY_RETURN();
   if (c->em == EM_FLIPOUT) trunk_dw1_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TW1_THREADS), TW1_LDS, c->st>>>(T);
   else trunk_dw1_kernel<EM_PLAIN><<<dim3(grid), dim3(TW1_THREADS), TW1_LDS, c->st>>>(T);
   HIP_TRY(hipGetLastError());
@@ -1352,14 +1395,16 @@ static int launch_trunk_dw2(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
   T.sign_in = c->nz.sign_in;
   T.sign_out = c->nz.sign_out;
   T.examples = (long)c->S * c->B;
-  T.gw_a = G.gw_a; T.gw_b = G.gw_b; T.gb_a = G.gb_a;
-  T.gw_stride = G.gw_stride; T.gb_stride = G.gb_stride;
+  const int sg = kind == 0 ? 1 : 2;
+  T.gw_a = ws_f(p, p->o_slab_a[sg]); T.gw_b = ws_f(p, p->o_slab_b[sg]); T.gb_a = ws_f(p, p->o_slab_ba[sg]);
+  T.gw_stride = p->slab_stride; T.gb_stride = p->slab_bstride;
   T.S = c->S; T.B = c->B; T.L = p->d.win_length;
   // kind 1 workgroups are small (6 waves, 52 KB of LDS): two share a CU
-  T.nsplit = std::max(1, std::min(c->B, (kind == 0 ? 256 : 512) / std::max(1, c->S)));
+  T.nsplit = trunk_dw_nsplit(c, sg);
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DW, kind == 0 ? 1 : 2, c->st);
   ps_.name(kind == 0 ? "trunk_dw2a_kernel<%d>" : "trunk_dw2b_kernel<%d>", c->em);
+  BNN_DRY_RETURN();
   if (kind == 0) {
     if (c->em == EM_FLIPOUT) {
       BNN_TRY(set_lds(trunk_dw2a_kernel<EM_FLIPOUT>, TW2A_LDS));
@@ -1400,6 +1445,7 @@ static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DX, 1, c->st);
   ps_.name("trunk_dx_kernel<%d>", c->em);
+  BNN_DRY_RETURN();
   if (c->em == EM_FLIPOUT) {
     BNN_TRY(set_lds(trunk_dx_kernel<EM_FLIPOUT>, TX_LDS));
     trunk_dx_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TX_THREADS), TX_LDS, c->st>>>(T);
@@ -1419,13 +1465,14 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
     const long rows = (long)c->B * p->d.win_length;
     u16* xh = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
     u16* xl = xh + (size_t)p->d.max_batch * p->d.win_length * 32;
-    x_planes_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xh, xl, rows, p->d.n_features, 32);
-    HIP_TRY(hipGetLastError());
+    if (!g_dry) {
+      x_planes_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xh, xl, rows, p->d.n_features, 32);
+      HIP_TRY(hipGetLastError());
+    }
   }
   for (int gi = trunk ? 3 : 0; gi < p->n_groups; ++gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, x, &A);
-    A.dbg = dbg_for(p, PK_FWD, gi);
     if (!bf)
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
@@ -1457,9 +1504,12 @@ static int do_head(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, float* preds,
   return 0;
 }
 
+static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c);
+
 static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   const size_t gwb = (size_t)c->S * p->img_total * 4, gbb = (size_t)c->S * p->bias_total * 4;
-  if (c->S == p->d.max_particles) {
+  if (g_dry) {
+  } else if (c->S == p->d.max_particles) {
     // gw_a | gw_b | gb_a | gb_b are back to back in the workspace: one fill
     HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gw_a), 0, (p->o_gb_b - p->o_gw_a) + gbb, c->st));
   } else {
@@ -1471,7 +1521,6 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   for (int gi = p->n_groups - 1; gi >= 0; --gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
-    A.dbg = dbg_for(p, PK_DW, gi);
     if (!A.g.is_dense && trunk_ok(p, c)) {
       // conv trunk: dz of MID / ACT1 (and the masked dz of ACT2) first, then the three dW kernels
       if (gi == 2) {
@@ -1481,6 +1530,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
         BNN_TRY(launch_trunk_dw2(p, a, c, 0));
       } else {
         BNN_TRY(launch_trunk_dw1(p, a, c));
+        BNN_TRY(reduce_trunk_slabs(p, c));
       }
       continue;
     }
@@ -1502,11 +1552,9 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     const bool conv_bf = p->d.prec == BNN_PREC_BF16X3 && !A.g.is_dense;
     if (conv_bf && (any_direct || any_pool)) {
       // one launch: direct and pooled branches, arg-max scatter included
-      A.dbg = dbg_for(p, PK_DX, gi);
       BNN_TRY(launch_conv_dx2(A, p->layers, c->em, c->st, &p->prof, gi));
       continue;
     }
-    A.dbg = dbg_for(p, PK_DX, gi);
     if (any_direct) {
       if (p->d.prec == BNN_PREC_F32)
         BNN_TRY(launch_dx<PrecF32>(A, c->em, 0, c->st, &p->prof, gi));
@@ -1516,7 +1564,6 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       else
         BNN_TRY(launch_dx<PrecBF>(A, c->em, 0, c->st, &p->prof, gi));
     }
-    A.dbg = dbg_for(p, PK_POOLBWD, gi);
     if (any_pool) {
       if (p->d.prec == BNN_PREC_F32)
         BNN_TRY(launch_dx<PrecF32>(A, c->em, 1, c->st, &p->prof, gi));
@@ -1527,6 +1574,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       const long nwin = (long)c->S * c->B;
       const int C = p->tens[tin].ctot, L = A.g.L;
       const long n = nwin * L * C;
+      if (g_dry) continue;
       ProfScope ps_(&p->prof, PK_POOLBWD, gi, c->st);
       ps_.name("pool_bwd_kernel");
       pool_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(
@@ -1534,6 +1582,30 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       HIP_TRY(hipGetLastError());
     }
   }
+  return 0;
+}
+
+// partial images of the trunk dW kernels -> the per-particle gradient images (weights: slots A and B, biases)
+static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c) {
+  if (g_dry) return 0;
+  ProfScope ps_(&p->prof, PK_FINALIZE, 1, c->st);
+  ps_.name("slab_reduce_kernel");
+  for (int which = 0; which < 3; ++which) {   // 0: slot A, 1: slot B (Flipout's dW part), 2: bias sums
+    if (which == 1 && c->em != EM_FLIPOUT) continue;
+    SlabReduceArgs R{};
+    for (int g = 0; g < 3; ++g) {
+      R.slab[g] = ws_f(p, which == 0 ? p->o_slab_a[g] : (which == 1 ? p->o_slab_b[g] : p->o_slab_ba[g]));
+      R.n[g] = trunk_dw_nsplit(c, g);
+    }
+    R.stride = which == 2 ? p->slab_bstride : p->slab_stride;
+    for (int l = 0; l < 10; ++l) R.lay_end[l] = which == 2 ? p->layers[l + 1].bias_off : p->layers[l + 1].w_off;
+    R.elems = R.lay_end[9];
+    R.out = ws_f(p, which == 0 ? p->o_gw_a : (which == 1 ? p->o_gw_b : p->o_gb_a));
+    R.out_stride = which == 2 ? p->bias_total : p->img_total;
+    R.S = c->S;
+    slab_reduce_kernel<<<dim3((unsigned)((R.elems + 255) / 256), c->S), dim3(256), 0, c->st>>>(R);
+  }
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -1617,6 +1689,33 @@ static int do_adam(BnnPlan* p, const BnnAdamArgs* ad, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // API: ops and steps
 // ------------------------------------------------------------------------------------------
+// Host-side plan validation (no device work, usable without a GPU): walks every launch function of a forward
+// [+ backward] pass for the given call geometry with the dry-run guard set, i.e. runs all their geometry checks
+// (DMA instructions vs plane / slot sizes, slot rings vs windows in flight, counted-wait ranges, LDS budgets).
+extern "C" int bnn_plan_validate(BnnPlan* p, int32_t mode, int32_t particles, int32_t batch, int32_t train) {
+  if (!p) return fail(BNN_E_INVALID, "null plan");
+  BnnElboArgs a{};
+  a.batch = batch;
+  a.particles = particles;
+  a.global_batch = batch;
+  a.dataset_size = 1.0;
+  a.prior_scale = 1.0;
+  a.mode_override = mode;
+  a.with_obs = 0;
+  const bool was_bound = p->bound;
+  p->bound = true;   // geometry only: no buffer is dereferenced under the guard
+  Ctx c;
+  int rc = make_ctx(p, &a, nullptr, nullptr, train != 0, &c);
+  if (rc == 0) {
+    g_dry = true;
+    rc = do_forward(p, &a, &c, nullptr);
+    if (rc == 0 && train) rc = do_backward(p, &a, &c);
+    g_dry = false;
+  }
+  p->bound = was_bound;
+  return rc;
+}
+
 extern "C" int bnn_sample_weights(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, void* stream) {
   Ctx c;
   BNN_TRY(make_ctx(p, a, nz, stream, true, &c));
@@ -1901,26 +2000,5 @@ extern "C" int bnn_profile_read(BnnPlan* p, int32_t* tags, double* ms, int64_t* 
   }
   *n = m;
   p->prof.used = 0;
-  return 0;
-}
-
-// diagnostics only (not part of the ABI of include/bayesrul_amd.h): phase time stamps of workgroup 0 of
-// the launch tagged kind * 16 + group (kinds: fwd 0, dx 1, dw 2, pooled dx 7); tag < 0 switches it off.
-extern "C" int bnn_debug_stamps_block(BnnPlan* p, int block) {
-  if (!p) return fail(BNN_E_INVALID, "null plan");
-  p->dbg_block = block;
-  return 0;
-}
-extern "C" int bnn_debug_stamps(BnnPlan* p, int tag) {
-  if (!p) return fail(BNN_E_INVALID, "null plan");
-  if (tag >= 0 && !p->dbg_buf) HIP_TRY(hipMalloc((void**)&p->dbg_buf, DBG_STAMP_BYTES));
-  if (p->dbg_buf) HIP_TRY(hipMemset(p->dbg_buf, 0, DBG_STAMP_BYTES));
-  p->dbg_tag = tag;
-  return 0;
-}
-extern "C" int bnn_debug_stamps_read(BnnPlan* p, void* dst, size_t bytes) {
-  if (!p || !p->dbg_buf) return fail(BNN_E_INVALID, "stamps not enabled");
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(dst, p->dbg_buf, bytes < (size_t)DBG_STAMP_BYTES ? bytes : (size_t)DBG_STAMP_BYTES, hipMemcpyDeviceToHost));
   return 0;
 }

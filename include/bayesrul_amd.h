@@ -134,6 +134,10 @@ int bnn_plan_site(const BnnPlan* plan, int32_t i, const char** name, int64_t* of
 /* layer table: image-channel count an injected sign_in row must have, and Cout */
 int bnn_plan_layer(const BnnPlan* plan, int32_t i, const char** name, int32_t* cin_img, int32_t* cout,
                    int32_t* is_conv);
+/* Host-side validation of every launch the plan would make for a call of this geometry (mode = BNN_MODE_* or -1 for the
+ * plan's own, train != 0: forward + backward): DMA instruction counts vs LDS plane / slot sizes, slot rings vs windows in
+ * flight, counted-wait ranges, LDS budgets.  No device work: usable without a GPU and before bnn_plan_bind. */
+int bnn_plan_validate(BnnPlan* plan, int32_t mode, int32_t particles, int32_t batch, int32_t train);
 /* debug/test access to intermediate activations of the last forward: tensor `which`
  * (see BNN_T_*), returns device pointer + row count + channel count */
 enum { BNN_T_ACT1 = 0, BNN_T_MID = 1, BNN_T_ACT2 = 2, BNN_T_H = 3, BNN_T_Z = 4,
