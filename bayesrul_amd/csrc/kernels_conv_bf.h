@@ -683,13 +683,20 @@ __global__ __launch_bounds__(DDX_WAVES * 64) void dense_dx_bf_kernel(const Group
   // Tiles in batches of TB: all weight fragments of a batch are fetched first, then its MFMAs and stores.  A
   // wave that loads and stores shares ONE in-order vmcnt, so the wait for the next batch's fragments also waits
   // for this batch's stores; paying that round trip once per TB tiles instead of once per tile is the point.
+  // A wave owns TB CONSECUTIVE tiles (its stores of a row then cover 128 contiguous bytes), and the group order is
+  // rotated by the window index so that the workgroups of a particle do not walk the same weight rows in lockstep.
   constexpr int TB = 4;
-  for (int t0 = wave; t0 < ntile; t0 += DDX_WAVES * TB) {
+  const int ngrp = (ntile + TB - 1) / TB;
+  const int rot = (int)(blockIdx.x % (unsigned)ngrp);
+  for (int g0 = wave; g0 < ngrp; g0 += DDX_WAVES) {
+    int grp = g0 + rot;
+    if (grp >= ngrp) grp -= ngrp;
+    const int t0 = grp * TB;
     bf16x8 wa[TB][2], wb[TB][2];
     uint32_t sw[TB][2];   // flipout: sign_in word of (row, 4 channels of this lane), per m-tile
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
-      const int t = t0 + DDX_WAVES * j;
+      const int t = t0 + j;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         wa[j][ks] = wb[j][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(DDX_WAVES * 64) void dense_dx_bf_kernel(const Group
     }
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
-      const int t = t0 + DDX_WAVES * j;
+      const int t = t0 + j;
       if (t >= ntile) break;
       const int c0 = t * 16;
       f32x4 acc_a[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};

@@ -56,6 +56,10 @@ __global__ __launch_bounds__(DF_NW * 64) void dense_fwd2_kernel(const GroupArgs 
   const bool is_loader = wave >= DF_NC;
   const int lw = wave - DF_NC;
   const int nchunk = F.nchunk;
+  // K chunks are walked in an order rotated by the window index: the workgroups of a particle would otherwise fetch
+  // the same weight lines from L2 in lockstep.  Step c works on chunk kc(c).
+  const int c_rot = win % nchunk;
+  auto kc = [&](int c) { const int k = c + c_rot; return k >= nchunk ? k - nchunk : k; };
   BNN_STAMP_DECL(A);
 
   if (is_loader) {
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(DF_NW * 64) void dense_fwd2_kernel(const GroupArgs 
       const int row = q >> 4, p = q & 15;
       const int c8 = p ^ (row & 15);
       const int srow = min(row, W.nvalid - 1);
-      a_src[i] = (const char*)((const u16*)(lw ? tin.lo : tin.p) + (long)(W.in_row0 + srow) * tin.ctot + c8 * 8);
+      a_src[i] = (const char*)((const u16*)(lw ? tin.lo : tin.p) + (long)(W.in_row0 + srow) * tin.ctot + c8 * 8 + c_rot * DF_CH);
       if (c8 < cw8_last) on_last |= 1u << i;
     }
     const uint32_t* sg_src = nullptr;
@@ -86,19 +90,20 @@ __global__ __launch_bounds__(DF_NW * 64) void dense_fwd2_kernel(const GroupArgs 
     }
     asm volatile("" : "+v"(sg_src), "+v"(sg_n));   // every ordinary load consumed before the DMA sequence
     const uint32_t lds0 = lds_addr(smem);
-    auto issue = [&](int c, int slot) {   // chunks must be issued in order 0, 1, 2, ...
+    auto issue = [&](int c, int slot) {   // steps must be issued in order 0, 1, 2, ...
       const uint32_t sbase = lds0 + (uint32_t)(slot * slot_bytes + lw * pbytes);
-      const bool last = c == nchunk - 1;
+      const int k = kc(c);
+      const bool last = k == nchunk - 1;
+      const int adv = last ? -(nchunk - 1) * DF_CH * 2 : DF_CH * 2;   // wrap to chunk 0 after the last one
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         uint32_t on = on_last;
         asm volatile("" : "+v"(on));
         if (!last || ((on >> i) & 1u)) dma16(a_src[i], sbase + (uint32_t)(i * 1024));
-        a_src[i] += DF_CH * 2;
+        a_src[i] += adv;
       }
       if constexpr (FO) {
-        if (c < sg_n) dma4(sg_src, lds0 + (uint32_t)(slot * slot_bytes + 2 * pbytes + lw * 256));
-        sg_src += 4;
+        if (k < sg_n) dma4(sg_src + 4 * k, lds0 + (uint32_t)(slot * slot_bytes + 2 * pbytes + lw * 256));
       }
     };
     constexpr int n_issue = 8 + (FO ? 1 : 0);
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(DF_NW * 64) void dense_fwd2_kernel(const GroupArgs 
   f32x4 acc_a[2], acc_b[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) acc_a[mt] = acc_b[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  load_w(0, w_hi[0], w_lo[0], w_b[0]);
+  load_w(c_rot, w_hi[0], w_lo[0], w_b[0]);
 
   __syncthreads();   // zero fill + table visible
   // Chunk c with the fragment set (whi, wlo, wb); the next chunk's fragments go to (nhi, nlo, nb).  The next
@@ -195,9 +200,9 @@ __global__ __launch_bounds__(DF_NW * 64) void dense_fwd2_kernel(const GroupArgs 
       asm volatile("" : "+v"(whi[ks]), "+v"(wlo[ks]));
       if constexpr (DUAL) asm volatile("" : "+v"(wb[ks]));
     }
-    if (c + 1 < nchunk) load_w(c + 1, nhi, nlo, nb);   // lands during this chunk's MFMAs
+    if (c + 1 < nchunk) load_w(kc(c + 1), nhi, nlo, nb);   // lands during this chunk's MFMAs
     if (has_job) {
-      const int nks = min(DF_CH, cin_p - c * DF_CH) >> 5;
+      const int nks = min(DF_CH, cin_p - kc(c) * DF_CH) >> 5;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks >= nks) break;

@@ -22,9 +22,10 @@
 
 enum { TX_NW = 15, TX_THREADS = TX_NW * 64, TX_NJ = 1 };   // 8 stage-B + 4 stage-A (TX_NJ tiles each) + 2 register loaders + 1 LDS-DMA loader
 enum {
-  TX_RS2 = 176,                        // bytes per row of the dz(ACT2) image: 80 channels + 16 pad
-  TX_P2 = IMG_ROWS * TX_RS2,           // 6,336
-  TX_PM = IMG_ROWS * TR_RSB,           // 9,792: dz(MID) image, 128 channels + 16 pad
+  TX_RS2 = 160,                        // bytes per row of the dz(ACT2) image: 80 channels, no pad: pitch 10 = 2 (mod 4) slots is
+                                       // conflict-free for the ds_read_b128 lane groups (see TR_RSB in kernels_trunk.h)
+  TX_P2 = IMG_ROWS * TX_RS2,           // 5,760
+  TX_PM = IMG_ROWS * TR_RSB,           // 10,368: dz(MID) image, 128 channels + 32 pad
   TX_SLOT = 2 * TX_P2,                 // dz2 | dz2 o s_out
   TX_O_SLOT = 0,                       // [3 slots]
   TX_O_DZM = 3 * TX_SLOT,              // [2 bufs][dz(MID), dz(MID) o s_out]

@@ -21,6 +21,7 @@
 #include "kernels_trunk.h"
 #include "kernels_trunk_bwd.h"
 #include "kernels_trunk_dw.h"
+#include "kernels_dense_ks.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -132,6 +133,8 @@ struct BnnPlan {
   // workspace layout (byte offsets)
   size_t ws_bytes = 0;
   size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
+  size_t o_dks = 0;                                // partial pre-activations of the K-split dense forward [chunk][rows][64]
+  long dks_rows = 0;
   long slab_stride = 0;
   int slab_bstride = 0;
   size_t o_layers, o_a_hi, o_a_lo, o_b, o_at, o_bt, o_bias_a, o_bias_b, o_gw_a, o_gw_b, o_gb_a, o_gb_b, o_eps, o_radr,
@@ -399,6 +402,10 @@ static void layout_workspace(BnnPlan* p) {
       p->o_slab_b[g] = take((size_t)slots[g] * p->slab_stride * 4);
       p->o_slab_ba[g] = take((size_t)slots[g] * p->slab_bstride * 4);
     }
+  }
+  if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
+    p->dks_rows = cap;
+    p->o_dks = take((size_t)((p->layers[10].cin + DK_CH - 1) / DK_CH) * cap * 64 * 4);
   }
   p->o_xplanes = take((size_t)4 * p->d.max_batch * p->d.win_length * 32 * 2);   // x hi | lo | pooled hi | pooled lo
   p->o_tens = o;
@@ -1278,6 +1285,84 @@ static int launch_dense_fwd2(const GroupArgs& A0, int em, hipStream_t st, Prof* 
   return 0;
 }
 
+// the wide dense layer of the Inception net: K-split, weight-stationary (kernels_dense_ks.h)
+static bool dense_ks_ok(const BnnPlan* p, const GroupArgs& A, int em) {
+  if (em == EM_LRT || p->o_dks == 0 || !dense_dma_ok(A)) return false;
+  const BranchDesc& br = A.g.br[0];
+  return br.cout == 64 && br.ntiles == 4 && br.cin_p >= 4 * DK_CH && (long)A.cg.S * A.cg.B <= p->dks_rows &&
+         (size_t)A.cg.S * A.cg.B * A.t[A.g.in_t].ctot * 2 < ((size_t)1 << 32);
+}
+
+static int launch_dense_ks_fwd(BnnPlan* p, const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  const BranchDesc& br = A.g.br[0];
+  const LayerDesc& ly = p->layers[br.layer];
+  DenseKsPlan F{};
+  F.nchunk = (br.cin_p + DK_CH - 1) / DK_CH;
+  F.nsplit = std::min(std::max(1, 512 / std::max(1, A.cg.S * F.nchunk)), A.cg.per_particle);
+  F.slab = ws_f(p, p->o_dks);
+  F.slab_stride = (long)A.cg.S * A.cg.B * 64;
+  F.ly = ly;
+  static_assert(DK_PLANE == 8 * 1024 && (DK_SLOTS & (DK_SLOTS - 1)) == 0, "a step plane is exactly the 8 DMA instructions a loader issues for it");
+  static_assert((DK_SLOTS - 2) * 10 <= 49, "counted-wait range");
+  static_assert(2 * DK_FWD_LDS <= 160 * 1024, "two workgroups per CU");
+  if (ly.sign_out_words > 2 || (br.cin_p & 31)) return fail(BNN_E_INVALID, "dense K-split forward: layer shape");
+  const int total = A.cg.S * F.nchunk * F.nsplit;
+  const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+  ProfScope ps_(pf, PK_FWD, gi, st);
+  ps_.name("dense_ks_fwd_kernel<%d>", em);
+  BNN_DRY_RETURN();
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(dense_ks_fwd_kernel<EM_PLAIN>, DK_FWD_LDS));
+    dense_ks_fwd_kernel<EM_PLAIN><<<dim3(grid), dim3(DK_NW * 64), DK_FWD_LDS, st>>>(A, F);
+  } else {
+    BNN_TRY(set_lds(dense_ks_fwd_kernel<EM_FLIPOUT>, DK_FWD_LDS));
+    dense_ks_fwd_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DK_NW * 64), DK_FWD_LDS, st>>>(A, F);
+  }
+  DenseKsFinArgs R{};
+  R.slab = F.slab;
+  R.slab_stride = F.slab_stride;
+  R.nchunk = F.nchunk;
+  R.rows = A.cg.S * A.cg.B;
+  R.B = A.cg.B;
+  R.bias = A.ws.bias_a + ly.bias_off + br.n_off;
+  R.bias_stride = A.ws.bias_stride_a;
+  R.relu = br.relu;
+  R.out = A.t[br.out_t];
+  R.out_off = br.out_off;
+  dense_ks_fin_kernel<<<dim3((unsigned)((R.rows * 16 + 255) / 256)), dim3(256), 0, st>>>(R);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// dX + dW of the wide dense layer in one launch (kernels_dense_ks.h)
+static int launch_dense_ks_bwd(BnnPlan* p, const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
+  GroupArgs A = A0;
+  const BranchDesc& br = A.g.br[0];
+  DenseKsPlan F{};
+  F.nchunk = (br.cin_p + DB_CH - 1) / DB_CH;
+  const int pairs = A.cg.S * F.nchunk;
+  F.nsplit = pairs >= 128 ? 1 : std::min(A.cg.per_particle, (256 + pairs - 1) / pairs);
+  F.ly = p->layers[br.layer];
+  static_assert(DB_LDS <= 160 * 1024 && DB_WAVES == 16, "one 16-wave workgroup per CU");
+  if ((br.cin_p & 15) || (A.t[br.dx_t].ctot & 3) || p->layers[br.layer].KPt < 64)
+    return fail(BNN_E_INVALID, "dense K-split backward: layer shape");
+  const int total = pairs * F.nsplit;
+  const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+  ProfScope ps_(pf, PK_DX, gi, st);
+  ps_.name("dense_ks_bwd_kernel<%d>", em);
+  BNN_DRY_RETURN();
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(dense_ks_bwd_kernel<EM_PLAIN>, DB_LDS));
+    dense_ks_bwd_kernel<EM_PLAIN><<<dim3(grid), dim3(DB_WAVES * 64), DB_LDS, st>>>(A, F);
+  } else {
+    BNN_TRY(set_lds(dense_ks_bwd_kernel<EM_FLIPOUT>, DB_LDS));
+    dense_ks_bwd_kernel<EM_FLIPOUT><<<dim3(grid), dim3(DB_WAVES * 64), DB_LDS, st>>>(A, F);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int launch_dense_dx_bf(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   const int zw = rup(A.g.br[0].cout, 32);
@@ -1477,6 +1562,8 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
       BNN_TRY(launch_conv_fwd_dma(A, p->layers, c->em, c->st, &p->prof, gi));
+    else if (dense_ks_ok(p, A, c->em))
+      BNN_TRY(launch_dense_ks_fwd(p, A, c->em, c->st, &p->prof, gi));
     else if (dense_dma_ok(A))
       BNN_TRY(launch_dense_fwd2(A, c->em, c->st, &p->prof, gi));
     else
@@ -1532,6 +1619,10 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
         BNN_TRY(launch_trunk_dw1(p, a, c));
         BNN_TRY(reduce_trunk_slabs(p, c));
       }
+      continue;
+    }
+    if (A.g.is_dense && dense_ks_ok(p, A, c->em) && A.g.br[0].dx_t >= 0 && A.t[A.g.br[0].out_t].fmt == TF_BF16) {
+      BNN_TRY(launch_dense_ks_bwd(p, A, c->em, c->st, &p->prof, gi));
       continue;
     }
     if (p->d.prec == BNN_PREC_F32)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Diagnostics (not part of the product): builds variants of the library with parts of the fused trunk kernels removed
-# (-DTR_ABL / -DTX_ABL bit masks, results wrong) and times the step with each.  Run on the GPU box:
+# (-DTR_ABL / -DTX_ABL / -DDK_ABL bit masks, results wrong) and times the step with each.  Run on the GPU box:
 #   bash tests/probes/ablate_gpu.sh "TR_ABL=1 TR_ABL=2 TX_ABL=1 ..."
 mkdir -p gpurun_out /tmp/abl
 cd bayesrul_amd/csrc
@@ -25,6 +25,6 @@ for line in buf.getvalue().splitlines():
     if line.startswith('{'):
         d = json.loads(line)
         k = d['kernel_ms_per_step']
-        print('$v', 'ms', round(d['ms_per_step'], 3), 'fwd0', k.get('fwd[0]'), 'dx1', k.get('dx[1]'), 'dw', k.get('dw[0]'), k.get('dw[1]'), k.get('dw[2]'))
+        print('$v', 'ms', round(d['ms_per_step'], 3), 'fwd0', k.get('fwd[0]'), 'dx1', k.get('dx[1]'), 'dw', k.get('dw[0]'), k.get('dw[1]'), k.get('dw[2]'), 'fwd3', k.get('fwd[3]'), 'dx3', k.get('dx[3]'))
 PY
 done
