@@ -180,18 +180,45 @@ __global__ __launch_bounds__(DK_NW * 64) void dense_ks_fwd_kernel(const GroupArg
 #pragma unroll
         for (int e = 0; e < 4; ++e) { sw[e] = s0[e]; sw[4 + e] = s1[e]; }
       }
-#pragma unroll
-      for (int ks = 0; ks < ((DK_ABL & 2) ? 0 : DK_KS); ++ks) {
-        if (ks >= nks) break;
-        const bf16x8 bh = *(const bf16x8*)(sl + k_o[ks]);
-        const bf16x8 bl = *(const bf16x8*)(sl + DK_PLANE + k_o[ks]);
+      auto rd = [&](int ks, bf16x8& bh, bf16x8& bl, u32x4& fm) {
+        bh = *(const bf16x8*)(sl + k_o[ks]);
+        bl = *(const bf16x8*)(sl + DK_PLANE + k_o[ks]);
+        if constexpr (FO) fm = __builtin_bit_cast(u32x4, lut[(sw[ks] >> (8 * g4)) & 0xffu]);   // byte g4 = this lane's 8 channels
+      };
+      auto mm = [&](int ks, bf16x8 bh, bf16x8 bl, u32x4 fm) {
         acc_a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bh, acc_a, 0, 0, 0);
         acc_hl = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bl, acc_hl, 0, 0, 0);
         acc_lh = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo[ks], bh, acc_lh, 0, 0, 0);
         if constexpr (FO) {
-          const u32x4 fm = __builtin_bit_cast(u32x4, lut[(sw[ks] >> (8 * g4)) & 0xffu]);   // byte g4 = this lane's 8 channels
           const u32x4 xb = __builtin_bit_cast(u32x4, bh) ^ fm;
           acc_b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_b[ks], __builtin_bit_cast(bf16x8, xb), acc_b, 0, 0, 0);
+        }
+      };
+      if constexpr (!(DK_ABL & 2)) {
+        bf16x8 bh0, bl0, bh1, bl1;
+        u32x4 fm0 = {0u, 0u, 0u, 0u}, fm1 = {0u, 0u, 0u, 0u};
+        if (nks == DK_KS) {
+          // full chunk: the operand reads of k-step ks+1 are in flight while the MFMAs of k-step ks issue (hipcc would
+          // sink every read next to its MFMA: two exposed LDS latencies per k-step)
+          rd(0, bh0, bl0, fm0);
+#pragma unroll
+          for (int ks = 0; ks < DK_KS; ks += 2) {
+            rd(ks + 1, bh1, bl1, fm1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ks, bh0, bl0, fm0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < DK_KS) rd(ks + 2, bh0, bl0, fm0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ks + 1, bh1, bl1, fm1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < DK_KS; ++ks) {   // last, shorter chunk (compile-time fragment indices: no scratch)
+            if (ks >= nks) break;
+            rd(ks, bh0, bl0, fm0);
+            mm(ks, bh0, bl0, fm0);
+          }
         }
       }
 #pragma unroll
@@ -242,19 +269,22 @@ __global__ __launch_bounds__(256) void dense_ks_fin_kernel(const DenseKsFinArgs 
 
 // ==========================================================================================
 // dense_ks_bwd_kernel : dX and dW of the wide dense layer for one (particle, 128-channel chunk, window split).
-//   16 waves, one barrier per 32-row window:
-//   waves  0..3  dX : two 16-channel tiles each, fragments of the transposed weight images in registers;
+//   13 waves, one barrier per 32-row window:
+//   waves 0..3   dX : two 16-channel tiles each, fragments of the transposed weight images in registers;
 //                     dX[row][c] = dz W^T + s_in (dz s_out) dW^T, stored as bf16 (a wave's two tiles are neighbours);
-//   waves  4..11 dW : (n-tile, half of the c-tiles): 4 (x2 for Flipout) tiles in registers across the windows,
-//                     both operands through transposed LDS reads; the chunk-0 workgroups also sum the bias gradient;
-//   waves 12..14    : dz loaders in rotation (a window each, three steps ahead): dY, Y, s_out -> registers ->
-//                     dz = dY [Y > 0] and dz s_out;
-//   wave  15        : LDS-DMA of the X chunk and its sign_in words into a ring of 6 windows, four windows ahead (HBM
-//                     latency under load is 2-3 us, a step far shorter), and the X s_in image of the next window.
+//   waves 4..7   dW : one n-tile x the chunk's 8 c-tiles each: 8 (x2 for Flipout) tiles in registers across the
+//                     windows, both operands through transposed LDS reads; the chunk-0 workgroups also sum the bias
+//                     gradient;
+//   waves 8..11     : image builders, EVERY step a quarter of the next window each (a VALU instruction costs its wave
+//                     4 cycles: one wave building a whole window was the step time): dz = dY [Y > 0] and dz s_out from
+//                     register loads three windows ahead (compile-time ring of 3 register sets), X s_in from the landed
+//                     X ring slot;
+//   wave  12        : LDS-DMA of the X chunk and its sign_in words into a ring of 6 windows, four windows ahead (HBM
+//                     latency under load is 2-3 us, a step far shorter).
 //   Images are 256-byte rows with the f128 XOR swizzle (for the DMA'd X: applied to the source address): conflict-free
-//   for the row reads of dX and the transposed reads of dW alike.
+//   for the transposed reads of dW; the row reads of dX are 2-way.
 // ==========================================================================================
-enum { DB_CH = 128, DB_ROWS = 32, DB_NX = 4, DB_ND = 8, DB_NZ = 3, DB_WAVES = DB_NX + DB_ND + DB_NZ + 1, DB_RING = 6, DB_AHEAD = 4 };
+enum { DB_CH = 128, DB_ROWS = 32, DB_NX = 4, DB_ND = 4, DB_NB = 4, DB_WAVES = DB_NX + DB_ND + DB_NB + 1, DB_RING = 6, DB_AHEAD = 4 };
 enum { DB_IMG = DB_ROWS * 256, DB_SGB = DB_ROWS * 4 * 4,
        DB_O_XR = 0, DB_O_SGR = DB_O_XR + DB_RING * DB_IMG, DB_O_X2 = DB_O_SGR + DB_RING * DB_SGB, DB_O_Z = DB_O_X2 + 2 * DB_IMG,
        DB_LDS = DB_O_Z + 2 * DB_IMG };
@@ -265,15 +295,10 @@ __device__ __forceinline__ tr_u32x4 sgn8v(tr_u32x4 v, uint32_t bits) {
   for (int e = 0; e < 4; ++e) v[e] ^= (((bits >> (2 * e)) & 1u) << 15) | (((bits >> (2 * e + 1)) & 1u) << 31);
   return v;
 }
-// keep the bf16 elements of g whose y is positive
+// keep the bf16 elements of g whose y (a ReLU output) is positive
 __device__ __forceinline__ tr_u32x4 relu_mask8(tr_u32x4 g, tr_u32x4 y) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const uint32_t yy = y[e];
-    const uint32_t lo = ((yy & 0x8000u) == 0 && (yy & 0x7fffu) != 0) ? 0xffffu : 0u;
-    const uint32_t hi = ((yy & 0x80000000u) == 0 && (yy & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
-    g[e] &= lo | hi;
-  }
+  for (int e = 0; e < 4; ++e) g[e] &= relu_mask2(y[e]);
   return g;
 }
 
@@ -295,14 +320,15 @@ __global__ __launch_bounds__(DB_WAVES * 64) void dense_ks_bwd_kernel(const Group
   const int B = A.cg.B, pp = A.cg.per_particle;
   const int cw = min(DB_CH, br.cin_p - chunk * DB_CH);   // multiple of 16
   const int nwl = split < pp ? (pp - split + F.nsplit - 1) / F.nsplit : 0;
+  // Barriers: P (window 0's X landed, before the builders make its images), Q (window 0's images visible), then B(k)
+  // per window.  Every role executes exactly these.
 
   if (wave == DB_WAVES - 1) {
     // =========================== X loader (LDS-DMA) ===========================
     const TensorRef tin = A.t[A.g.in_t];
     const uint32_t* sgi = A.nz.sign_in + ly.sign_in_off * A.nz.examples;
-    int siw = ly.sign_in_words;
-    int cw8 = cw >> 3;
-    asm volatile("" : "+v"(sgi), "+v"(siw), "+v"(cw8));   // table loads consumed before the DMA sequence (see the forward)
+    const int siw = ly.sign_in_words;
+    const int cw8 = cw >> 3;
     const int r4 = lane >> 4, pc = lane & 15;
     const uint32_t rowb = (uint32_t)tin.ctot * 2u;
     uint32_t cb[4], act = 0;
@@ -333,100 +359,106 @@ __global__ __launch_bounds__(DB_WAVES * 64) void dense_ks_bwd_kernel(const Group
         }
       }
     };
-    auto build = [&](int k, int slot) {   // X s_in image of window k from its landed ring slot
-      if constexpr (FO && !(DK_ABL & 32)) {
-        const char* xr = smem + DB_O_XR + slot * DB_IMG;
-        const uint32_t* sg = (const uint32_t*)(smem + DB_O_SGR + slot * DB_SGB);
-        char* x2 = smem + DB_O_X2 + (k & 1) * DB_IMG;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int e = j * 64 + lane;
-          const int row = e >> 4, pp_ = e & 15;
-          const int c = pp_ ^ f128(row);
-          const tr_u32x4 v = *(const tr_u32x4*)(xr + e * 16);
-          const uint32_t word = sg[row * 4 + (c >> 2)];
-          *(tr_u32x4*)(x2 + e * 16) = sgn8v(v, word >> (8 * (c & 3)));
-        }
-      }
-    };
     constexpr int n_issue = 8 + (FO ? 2 : 0);
     for (int j = 0; j < DB_AHEAD; ++j)
       if (j < nwl) issue(j, j);
-    if (nwl > 0) {
-      if constexpr (DK_ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
-      BNN_WAIT_VMCNT_WIDE((min(nwl, DB_AHEAD) - 1) * n_issue);   // window 0 landed
-      build(0, 0);
-    }
-    int slot_n = 1;                      // ring slot of window k + 1
+    if constexpr (DK_ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
+    BNN_WAIT_VMCNT_WIDE(max(0, min(nwl, DB_AHEAD) - 1) * n_issue);   // window 0 landed
+    lds_barrier();   // P
+    lds_barrier();   // Q
     int slot_i = DB_AHEAD % DB_RING;     // ring slot of window k + DB_AHEAD
     for (int k = 0; k < nwl; ++k) {
-      // window k+1 landed; windows k+2 .. k+3 may stay in flight
+      // window k+1 landed (the builders read it during step k); windows k+2 .. k+3 may stay in flight
       const int fly = max(0, min(k + DB_AHEAD - 1, nwl - 1) - (k + 1)) * n_issue;
       if constexpr (DK_ABL & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else
       BNN_WAIT_VMCNT_WIDE(fly);
       lds_barrier();   // B(k)
       if (k + DB_AHEAD < nwl) issue(k + DB_AHEAD, slot_i);   // slot of window k-2: consumed
-      if (k + 1 < nwl) build(k + 1, slot_n);
-      slot_n = slot_n + 1 == DB_RING ? 0 : slot_n + 1;
       slot_i = slot_i + 1 == DB_RING ? 0 : slot_i + 1;
     }
     return;
   }
   if (wave >= DB_NX + DB_ND) {
-    // =========================== dz loaders ===========================
-    const int lw = wave - (DB_NX + DB_ND);
+    // =========================== image builders ===========================
+    asm volatile("" ::: "memory");
+    const int bw = wave - (DB_NX + DB_ND);
     const TensorRef tg = A.t[br.out_t + T_GRAD], ty = A.t[br.out_t];
     const uint32_t* sgo = A.nz.sign_out + ly.sign_out_off * A.nz.examples;
     const int sow = ly.sign_out_words;
-    tr_u32x4 dy[4], yy[4];
-    uint32_t so[4];
-    int nv_w = 0;   // valid rows of the window held in registers
-    // loads are unconditional (pad rows re-read the last valid one, masked when the image is written): a load under a
-    // branch is waited for at the join, i.e. immediately
-    const int c8 = lane & 7, r8 = lane >> 3;
+    // dz unit of this lane: (row zrow, 8-channel piece c8).  Loads are unconditional (pad rows re-read the last valid
+    // one, masked when the image is written): a load under a branch is waited for at the join, i.e. immediately.
+    const int c8 = lane & 7, zrow = bw * 8 + (lane >> 3);
     const bool c_on = c8 * 8 < br.cout;
     const int cc8 = c_on ? c8 : 0;
     const int bit0 = br.n_off + cc8 * 8;
-    auto load = [&](int k) {
+    const int zo = zrow * 256 + ((c8 ^ f128(zrow)) << 4);
+    auto load = [&](int k, tr_u32x4& dy, tr_u32x4& yy, uint32_t& so, int& nvw) {
       const int wl = split + k * F.nsplit;
       const long row0 = (long)s * B + wl * DB_ROWS;
-      const int nv = min(DB_ROWS, B - wl * DB_ROWS);
-      nv_w = nv;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = min(8 * j + r8, nv - 1);
-        const long o = (row0 + row) * tg.ctot + br.out_off + cc8 * 8;
-        dy[j] = *(const tr_u32x4*)((const u16*)tg.p + o);
-        yy[j] = *(const tr_u32x4*)((const u16*)ty.p + o);
-        if constexpr (FO) so[j] = sgo[(row0 + row) * sow + (bit0 >> 5)];
+      nvw = min(DB_ROWS, B - wl * DB_ROWS);
+      const long o = (row0 + min(zrow, nvw - 1)) * tg.ctot + br.out_off + cc8 * 8;
+      if constexpr (!(DK_ABL & 64)) {
+        dy = *(const tr_u32x4*)((const u16*)tg.p + o);
+        yy = *(const tr_u32x4*)((const u16*)ty.p + o);
+        if constexpr (FO) so = sgo[(row0 + min(zrow, nvw - 1)) * sow + (bit0 >> 5)];
       }
     };
-    auto write = [&](int slot) {
-      char* zi = smem + DB_O_Z + slot * DB_IMG;
+    // images of window k: the lane's dz unit from a register set, two pieces of X s_in from the window's ring slot
+    auto make = [&](int k, int ring, tr_u32x4 dy, tr_u32x4 yy, uint32_t so, int nvw) {
+      char* zi = smem + DB_O_Z + (k & 1) * DB_IMG;
+      tr_u32x4 g = dy;
+      if (br.relu) g = relu_mask8(g, yy);
+      if (zrow >= nvw || !c_on) g = tr_u32x4{0u, 0u, 0u, 0u};
+      *(tr_u32x4*)(zi + zo) = g;
+      if constexpr (FO) {
+        *(tr_u32x4*)(zi + (zo ^ 128)) = sgn8v(g, so >> (bit0 & 31));
+        if constexpr (!(DK_ABL & 32)) {
+          const char* xr = smem + DB_O_XR + ring * DB_IMG;
+          const uint32_t* sg = (const uint32_t*)(smem + DB_O_SGR + ring * DB_SGB);
+          char* x2 = smem + DB_O_X2 + (k & 1) * DB_IMG;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = 8 * j + r8;
-        tr_u32x4 g = dy[j];
-        if (br.relu) g = relu_mask8(g, yy[j]);
-        if (row >= nv_w || !c_on) g = tr_u32x4{0u, 0u, 0u, 0u};
-        *(tr_u32x4*)(zi + row * 256 + ((c8 ^ f128(row)) << 4)) = g;
-        if constexpr (FO) *(tr_u32x4*)(zi + row * 256 + (((8 + c8) ^ f128(row)) << 4)) = sgn8v(g, so[j] >> (bit0 & 31));
+          for (int j = 0; j < 2; ++j) {
+            const int e = (bw * 2 + j) * 64 + lane;
+            const int row = e >> 4, c = (e & 15) ^ f128(row);
+            const tr_u32x4 v = *(const tr_u32x4*)(xr + e * 16);
+            const uint32_t word = sg[row * 4 + (c >> 2)];
+            *(tr_u32x4*)(x2 + e * 16) = sgn8v(v, word >> (8 * (c & 3)));
+          }
+        }
       }
     };
-    if (lw < nwl) load(lw);
-    int turn = 0;   // k mod DB_NZ
-    for (int k = 0; k < nwl; ++k) {
-      if (turn == lw) {
-        write(k & 1);   // after barrier k-1: window k-2 (same slot) is consumed
-        if (k + DB_NZ < nwl) load(k + DB_NZ);
-      }
-      lds_barrier();   // B(k): window k visible
-      turn = turn + 1 == DB_NZ ? 0 : turn + 1;
+    tr_u32x4 dy0 = {0u, 0u, 0u, 0u}, yy0 = dy0, dy1 = dy0, yy1 = dy0, dy2 = dy0, yy2 = dy0;
+    uint32_t so0 = 0, so1 = 0, so2 = 0;
+    int nv0 = 0, nv1 = 0, nv2 = 0;
+    if (0 < nwl) load(0, dy0, yy0, so0, nv0);
+    if (1 < nwl) load(1, dy1, yy1, so1, nv1);
+    if (2 < nwl) load(2, dy2, yy2, so2, nv2);
+    lds_barrier();   // P: window 0's X landed
+    if (nwl > 0) {
+      make(0, 0, dy0, yy0, so0, nv0);
+      if (3 < nwl) load(3, dy0, yy0, so0, nv0);
     }
+    lds_barrier();   // Q
+    // step k (after B(k)): images of window k+1 from register set (k+1) % 3, then that set is reloaded with window k+4
+    int ring = 1;
+#define DB_STEP(K, DY, YY, SO, NV)                          \
+  do {                                                      \
+    lds_barrier();                                          \
+    if ((K) + 1 < nwl) {                                    \
+      make((K) + 1, ring, DY, YY, SO, NV);                  \
+      if ((K) + 4 < nwl) load((K) + 4, DY, YY, SO, NV);     \
+    }                                                       \
+    ring = ring + 1 == DB_RING ? 0 : ring + 1;              \
+  } while (0)
+    for (int k = 0; k < nwl; k += 3) {
+      DB_STEP(k, dy1, yy1, so1, nv1);
+      if (k + 1 < nwl) DB_STEP(k + 1, dy2, yy2, so2, nv2);
+      if (k + 2 < nwl) DB_STEP(k + 2, dy0, yy0, so0, nv0);
+    }
+#undef DB_STEP
     // nothing is in flight here, but hipcc's bookkeeping says otherwise (the loads of the last loop body), and its
     // structurised control flow lets that state reach the DMA role's code: close it with a use of every destination
-#pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(dy[j]), "v"(yy[j]), "v"(so[j]));
+    asm volatile("" ::"v"(dy0), "v"(yy0), "v"(so0), "v"(dy1), "v"(yy1), "v"(so1), "v"(dy2), "v"(yy2), "v"(so2));
     return;
   }
 
@@ -466,6 +498,8 @@ __global__ __launch_bounds__(DB_WAVES * 64) void dense_ks_bwd_kernel(const Group
         asm volatile("" : "+v"(wa[j][ks]));
         if constexpr (FO) asm volatile("" : "+v"(wb[j][ks]));
       }
+    lds_barrier();   // P
+    lds_barrier();   // Q
     int ring = 0;
     for (int k = 0; k < nwl; ++k) {
       const int wl = split + k * F.nsplit;
@@ -513,12 +547,14 @@ __global__ __launch_bounds__(DB_WAVES * 64) void dense_ks_bwd_kernel(const Group
   }
 
   // =========================== dW waves ===========================
-  const int w8 = wave - DB_NX;
-  const int nt = w8 >> 1, ct0 = (w8 & 1) * 4;
-  const bool bias_job = chunk == 0 && (w8 & 1) == 0;
-  f32x4 acc_a[4], acc_b[4], acc_bias = {0.f, 0.f, 0.f, 0.f};
+  const int nt = wave - DB_NX;
+  const bool bias_job = chunk == 0;
+  f32x4 acc_a[8], acc_b[FO ? 8 : 1], acc_bias = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < 4; ++c) acc_a[c] = acc_b[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < 8; ++c) {
+    acc_a[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (FO) acc_b[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const s16x8 ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
   const int gq = lane >> 4, qq = (lane >> 2) & 3, p4 = lane & 3;
@@ -527,6 +563,8 @@ __global__ __launch_bounds__(DB_WAVES * 64) void dense_ks_bwd_kernel(const Group
   const int ho = 8 * (p4 & 1);
   const int ca = nt * 2 + (p4 >> 1);
   const int a0 = r0 * 256 + ((ca ^ f0) << 4) + ho, a1 = (r0 + 4) * 256 + ((ca ^ f1) << 4) + ho;
+  lds_barrier();   // P
+  lds_barrier();   // Q
   int ring = 0;
   for (int k = 0; k < nwl; ++k) {
     const char* zi = smem + DB_O_Z + (k & 1) * DB_IMG;
@@ -538,9 +576,9 @@ __global__ __launch_bounds__(DB_WAVES * 64) void dense_ks_bwd_kernel(const Group
     if constexpr (FO) fa2 = tr_frag2(zi + (a0 ^ 128), zi + (a1 ^ 128));
     if (bias_job) acc_bias = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, ones, acc_bias, 0, 0, 0);
 #pragma unroll
-    for (int c = 0; c < ((DK_ABL & 256) ? 0 : 4); ++c) {
-      if ((ct0 + c) * 16 >= cw) break;
-      const int cb = (ct0 + c) * 2 + (p4 >> 1);
+    for (int c = 0; c < ((DK_ABL & 256) ? 0 : 8); ++c) {
+      if (c * 16 >= cw) break;
+      const int cb = c * 2 + (p4 >> 1);
       const int b0 = r0 * 256 + ((cb ^ f0) << 4) + ho, b1 = (r0 + 4) * 256 + ((cb ^ f1) << 4) + ho;
       const bf16x8 fb = tr_frag2(xi + b0, xi + b1);
       acc_a[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc_a[c], 0, 0, 0);
@@ -556,9 +594,9 @@ __global__ __launch_bounds__(DB_WAVES * 64) void dense_ks_bwd_kernel(const Group
   const int i4 = 4 * (lane >> 4), jc = lane & 15;
   const bool direct = F.nsplit == 1;   // one workgroup per (particle, chunk): its tiles ARE the gradient
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int cc = chunk * DB_CH + (ct0 + c) * 16 + jc;
-    if ((ct0 + c) * 16 >= cw) break;
+  for (int c = 0; c < 8; ++c) {
+    const int cc = chunk * DB_CH + c * 16 + jc;
+    if (c * 16 >= cw) break;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = nt * 16 + i4 + r;

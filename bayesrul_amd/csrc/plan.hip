@@ -1344,7 +1344,8 @@ static int launch_dense_ks_bwd(BnnPlan* p, const GroupArgs& A0, int em, hipStrea
   const int pairs = A.cg.S * F.nchunk;
   F.nsplit = pairs >= 128 ? 1 : std::min(A.cg.per_particle, (256 + pairs - 1) / pairs);
   F.ly = p->layers[br.layer];
-  static_assert(DB_LDS <= 160 * 1024 && DB_WAVES == 16, "one 16-wave workgroup per CU");
+  static_assert(DB_LDS <= 160 * 1024 && DB_WAVES <= 16, "one workgroup per CU");
+  static_assert(DB_AHEAD * 10 <= 49 && DB_RING >= DB_AHEAD + 2, "counted-wait range / ring: windows k-1 .. k+4 are live");
   if ((br.cin_p & 15) || (A.t[br.dx_t].ctot & 3) || p->layers[br.layer].KPt < 64)
     return fail(BNN_E_INVALID, "dense K-split backward: layer shape");
   const int total = pairs * F.nsplit;
