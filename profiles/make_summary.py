@@ -2,7 +2,8 @@
 """Builds the committed rocprofv3 summaries of a round from the raw output under gpurun_out/ (scratch; written by
 tests/prof_gpu.sh on the MI355X box).
 
-usage: python profiles/make_summary.py <tag>      e.g. r02_flipout_conv_s10
+usage: python profiles/make_summary.py <tag> [src]     e.g. r02_flipout_conv_s10 [gpurun_out/keep_flipout_conv_s10]
+  (src defaults to gpurun_out: the raw output of the last tests/prof_gpu.sh; tests/round_gpu.sh keeps one copy per workload)
   gpurun_out/prof_stats/*/*_kernel_stats.csv          -> profiles/<tag>_kernel_stats.csv   (copied)
   gpurun_out/prof_fetch, prof_write/*/*_counter_collection.csv (separate --pmc FETCH_SIZE / WRITE_SIZE passes)
       -> profiles/<tag>_pmc_summary.csv: per kernel symbol the mean FETCH_SIZE / WRITE_SIZE per launch (KB, as rocprofv3
@@ -22,11 +23,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+SRC = os.path.join(ROOT, sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out")
 out = os.path.join(ROOT, "profiles")
 
 
 def newest(dirname):
-    fs = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", dirname, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    fs = sorted(glob.glob(os.path.join(SRC, dirname, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     return fs[-1:] if fs else []
 
 
@@ -44,7 +46,7 @@ def per_kernel(dirname):
 def steps_of(logname):
     """warm-up + timed + per-kernel pass steps of the profiled bench command (for launches per step)"""
     try:
-        for line in open(os.path.join(ROOT, "gpurun_out", logname)):
+        for line in open(os.path.join(SRC, logname)):
             if line.startswith("{"):
                 import json
                 d = json.loads(line)
@@ -54,7 +56,7 @@ def steps_of(logname):
     return None
 
 
-st = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "prof_stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+st = sorted(glob.glob(os.path.join(SRC, "prof_stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if st:
     shutil.copy(st[-1], os.path.join(out, f"{tag}_kernel_stats.csv"))
 fe, wr = per_kernel("prof_fetch"), per_kernel("prof_write")
