@@ -324,54 +324,58 @@ struct HeadArgs {
   int objective;    // 0: TyXe HeteroskedasticGaussian (A11); 1: HNN gaussian_nll_loss; 2: NN mse  (frequentist.py:39-48,173-178)
 };
 
+// one example row of the head: predictions, log-likelihood term (returned) and d(-ll)/dz (g0, g1; also stored when A.dz)
+__device__ __forceinline__ double head_row(const HeadArgs& A, int s, int idx, float& g0o, float& g1o) {
+  double ll = 0.0;
+  g0o = g1o = 0.f;
+  const long r = (long)s * A.B + idx;
+  const float z0 = A.z[r * 2], z1 = A.z[r * 2 + 1];
+  const float sp0 = softplus_t(z0), sp1 = softplus_t(z1);
+  const bool p0 = sp0 > 1e-9f, p1 = sp1 > 1e-9f;
+  const float o0 = p0 ? sp0 : 1e-9f, o1 = p1 ? sp1 : 1e-9f;
+  if (A.preds) {
+    A.preds[r * 2] = o0;
+    A.preds[r * 2 + 1] = o1;
+  }
+  if (A.with_obs && A.objective != 0) {
+    // frequentist siblings: ll = -loss_b; scale = o1 (the net's own softplus + threshold only)
+    const float d = o0 - A.y[idx];
+    float g0, g1 = 0.f;
+    if (A.objective == 1) {
+      const float var = fmaxf(o1 * o1, 1e-6f);   // F.gaussian_nll_loss: var.clamp_(min=eps) under no_grad
+      ll = -0.5 * ((double)logf(var) + (double)(d * d) / (double)var);
+      g0 = d / var;
+      g1 = (0.5f / var - 0.5f * d * d / (var * var)) * 2.f * o1;   // the clamp carries no gradient: d var / d o1 = 2 o1
+    } else {
+      ll = -(double)(d * d);
+      g0 = 2.f * d;
+    }
+    g0o = p0 ? g0 * dsoftplus_t(z0) : 0.f;
+    g1o = p1 ? g1 * dsoftplus_t(z1) : 0.f;
+  } else if (A.with_obs) {
+    const float sc = softplus_t(o1);
+    const float d = A.y[idx] - o0;
+    ll = -(double)(d * d) / (2.0 * (double)sc * (double)sc) - (double)logf(sc) - 0.9189385332046727;
+    // d(-ll)/d o0 = -(y - o0)/s^2 ; d(-ll)/d s = -(y-o0)^2/s^3 + 1/s
+    const float g0 = -d / (sc * sc);
+    const float gs = -(d * d) / (sc * sc * sc) + 1.f / sc;
+    const float g1 = gs * dsoftplus_t(o1);
+    g0o = p0 ? g0 * dsoftplus_t(z0) : 0.f;
+    g1o = p1 ? g1 * dsoftplus_t(z1) : 0.f;
+  }
+  if (A.dz) {
+    A.dz[r * 2] = g0o;
+    A.dz[r * 2 + 1] = g1o;
+  }
+  return ll;
+}
+
 __global__ void head_nll_kernel(const HeadArgs A) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   double ll = 0.0;
-  if (idx < A.B) {
-    const long r = (long)s * A.B + idx;
-    const float z0 = A.z[r * 2], z1 = A.z[r * 2 + 1];
-    const float sp0 = softplus_t(z0), sp1 = softplus_t(z1);
-    const bool p0 = sp0 > 1e-9f, p1 = sp1 > 1e-9f;
-    const float o0 = p0 ? sp0 : 1e-9f, o1 = p1 ? sp1 : 1e-9f;
-    if (A.preds) {
-      A.preds[r * 2] = o0;
-      A.preds[r * 2 + 1] = o1;
-    }
-    if (A.with_obs && A.objective != 0) {
-      // frequentist siblings: ll = -loss_b; scale = o1 (the net's own softplus + threshold only)
-      const float d = o0 - A.y[idx];
-      float g0, g1 = 0.f;
-      if (A.objective == 1) {
-        const float var = fmaxf(o1 * o1, 1e-6f);   // F.gaussian_nll_loss: var.clamp_(min=eps) under no_grad
-        ll = -0.5 * ((double)logf(var) + (double)(d * d) / (double)var);
-        g0 = d / var;
-        g1 = (0.5f / var - 0.5f * d * d / (var * var)) * 2.f * o1;   // the clamp carries no gradient: d var / d o1 = 2 o1
-      } else {
-        ll = -(double)(d * d);
-        g0 = 2.f * d;
-      }
-      if (A.dz) {
-        A.dz[r * 2] = p0 ? g0 * dsoftplus_t(z0) : 0.f;
-        A.dz[r * 2 + 1] = p1 ? g1 * dsoftplus_t(z1) : 0.f;
-      }
-    } else if (A.with_obs) {
-      const float sc = softplus_t(o1);
-      const float d = A.y[idx] - o0;
-      ll = -(double)(d * d) / (2.0 * (double)sc * (double)sc) - (double)logf(sc) - 0.9189385332046727;
-      if (A.dz) {
-        // d(-ll)/d o0 = -(y - o0)/s^2 ; d(-ll)/d s = -(y-o0)^2/s^3 + 1/s
-        const float g0 = -d / (sc * sc);
-        const float gs = -(d * d) / (sc * sc * sc) + 1.f / sc;
-        const float g1 = gs * dsoftplus_t(o1);
-        A.dz[r * 2] = p0 ? g0 * dsoftplus_t(z0) : 0.f;
-        A.dz[r * 2 + 1] = p1 ? g1 * dsoftplus_t(z1) : 0.f;
-      }
-    } else if (A.dz) {
-      A.dz[r * 2] = 0.f;
-      A.dz[r * 2 + 1] = 0.f;
-    }
-  }
+  float g0, g1;
+  if (idx < A.B) ll = head_row(A, s, idx, g0, g1);
   __shared__ double red[4];
   ll = wave_sum_d(ll);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ll;
@@ -385,7 +389,7 @@ __global__ void head_nll_kernel(const HeadArgs A) {
 
 // loss = (1/S) sum_s [ c*KL_s - c*(N/B)*ll_s ]   (A5 / A6); written to out + grad[2P], grad[2P+1]
 struct LossArgs {
-  const double* kl_acc;
+  double* kl_acc;
   const double* ll_acc;
   int S;
   int radial;
@@ -393,10 +397,12 @@ struct LossArgs {
   double kl_weight;   // 1: ELBO; 0: the frequentist objectives (loss = -c * n_over_b * ll)
   float* loss; float* kl; float* ll;
   float* grad_tail;  // &grad[2P] or null
+  int n_acc;         // doubles to zero after use (all accumulators: 2 * (max_particles + 1))
 };
 
-__global__ void finish_loss_kernel(const LossArgs A) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one thread: the loss scalars from the accumulators.  REARM: the accumulators are zeroed for the next call (the host
+// then skips its memset: plan.hip acc_clean)
+__device__ __forceinline__ void finish_loss_dev(const LossArgs& A) {
   double kl = 0, ll = 0;
   for (int s = 0; s < A.S; ++s) {
     kl += A.radial ? A.kl_acc[s] : A.kl_acc[0];
@@ -412,6 +418,12 @@ __global__ void finish_loss_kernel(const LossArgs A) {
     A.grad_tail[0] = (float)loss;
     A.grad_tail[1] = (float)kl;
   }
+  for (int k = 0; k < A.n_acc; ++k) A.kl_acc[k] = 0.0;   // kl | ll accumulators are back to back
+}
+
+__global__ void finish_loss_kernel(const LossArgs A) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  finish_loss_dev(A);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -430,10 +442,13 @@ struct FinalizeArgs {
   float c;          // KL scale
   float prior_loc, prior_scale;
   float* grad;      // [2P]
+  LossArgs loss;    // fused_loss: thread 0 of workgroup 0 also finishes the loss scalars (the accumulators are complete:
+  int fused_loss;   // the head ran earlier on the stream)
 };
 
 __global__ void grad_finalize_kernel(const FinalizeArgs A) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (A.fused_loss && e == 0) finish_loss_dev(A.loss);
   if (e >= A.T.P) return;
   const int si = find_site(A.T, e);
   const SiteDesc sd = A.T.site[si];

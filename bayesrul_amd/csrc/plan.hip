@@ -22,6 +22,7 @@
 #include "kernels_trunk_bwd.h"
 #include "kernels_trunk_dw.h"
 #include "kernels_dense_ks.h"
+#include "kernels_mlp.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -135,6 +136,9 @@ struct BnnPlan {
   size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
   size_t o_dks = 0;                                // partial pre-activations of the K-split dense forward [chunk][rows][64]
   long dks_rows = 0;
+  bool acc_clean = false;                          // the loss accumulators are zero (the last finish_loss re-armed them)
+  size_t o_mlp_x = 0, o_mlp_dz4 = 0;               // fused Linear-net kernels: x hi plane [B][544]; dz / dz q of the last layer
+  int mlp = 0;
   long slab_stride = 0;
   int slab_bstride = 0;
   size_t o_layers, o_a_hi, o_a_lo, o_b, o_at, o_bt, o_bias_a, o_bias_b, o_gw_a, o_gw_b, o_gb_a, o_gb_b, o_eps, o_radr,
@@ -403,6 +407,12 @@ static void layout_workspace(BnnPlan* p) {
       p->o_slab_ba[g] = take((size_t)slots[g] * p->slab_bstride * 4);
     }
   }
+  if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_LINEAR && p->layers[0].KP == ML_K0 && p->layers[0].cout == ML_N0 &&
+      p->layers[1].cout == ML_N1 && p->layers[2].cout == ML_N2 && p->layers[3].cout == ML_N3 && p->layers[4].cout == ML_N4) {
+    p->mlp = 1;
+    p->o_mlp_x = take((size_t)p->d.max_batch * ML_K0 * 2);
+    p->o_mlp_dz4 = take((size_t)cap * 8 * 2 * 2);
+  }
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
     p->dks_rows = cap;
     p->o_dks = take((size_t)((p->layers[10].cin + DK_CH - 1) / DK_CH) * cap * 64 * 4);
@@ -581,6 +591,8 @@ struct Ctx {
   int objective = 0;   // 0 ELBO; 1 / 2: frequentist objectives (bnn_det_step)
   NoiseRefs nz{};
   int s_base = 0;  // particle offset for noise streams (predict chunks)
+  bool head_fused = false;       // bnn_elbo_step on the fused Linear-net path: the head runs inside the backward's first kernel
+  float* head_preds = nullptr;
 };
 
 static int em_of(int mode) { return mode == BNN_MODE_LRT ? EM_LRT : (mode == BNN_MODE_FLIPOUT ? EM_FLIPOUT : EM_PLAIN); }
@@ -700,7 +712,8 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
 // sample weights
 // ------------------------------------------------------------------------------------------
 static int do_sample(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
-  HIP_TRY(hipMemsetAsync(ws_f(p, p->o_acc), 0, sizeof(double) * 2 * (p->d.max_particles + 1), c->st));
+  if (!p->acc_clean) HIP_TRY(hipMemsetAsync(ws_f(p, p->o_acc), 0, sizeof(double) * 2 * (p->d.max_particles + 1), c->st));
+  p->acc_clean = false;
   PrepArgs A{};
   A.T = p->ptab;
   A.layers = (const LayerDesc*)((char*)p->bufs.workspace + p->o_layers);
@@ -1379,6 +1392,128 @@ static int launch_dense_dx_bf(const GroupArgs& A0, int em, hipStream_t st, Prof*
   return 0;
 }
 
+// fused LRT kernels of the Linear net (kernels_mlp.h)
+static bool mlp_ok(const BnnPlan* p, const Ctx* c) { return p->mlp && c->em == EM_LRT; }
+
+static void fill_mlp_plan(const BnnPlan* p, MlpPlan* M) {
+  const int tid[5] = {TI_H, TI_H2, TI_H3, TI_H4, TI_Z};
+  for (int l = 0; l < 5; ++l) {
+    M->ly[l] = p->layers[l];
+    M->h[l] = tens_ref(p, tid[l], 0);
+    M->g[l] = tens_ref(p, tid[l], 1);
+    M->q[l] = tens_ref(p, tid[l], 2);
+  }
+  M->xhi = (u16*)((char*)p->bufs.workspace + p->o_mlp_x);
+  M->dz4 = (u16*)((char*)p->bufs.workspace + p->o_mlp_dz4);
+  M->dz4_plane = p->cap_windows * 8;
+}
+
+static int launch_mlp_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
+  GroupArgs A;
+  fill_group_args(p, a, c, 0, x, &A);
+  static thread_local MlpPlan M;
+  fill_mlp_plan(p, &M);
+  static_assert(ML0_LDS <= 160 * 1024 && ML14_LDS <= 160 * 1024 && MX_LDS <= 160 * 1024 && MW_LDS <= 160 * 1024, "LDS budgets");
+  if (A.t[T_X].ctot != 540 || (A.t[T_X].ctot & 3)) return fail(BNN_E_INVALID, "fused Linear net: %d input features", A.t[T_X].ctot);
+  {
+    ProfScope ps_(&p->prof, PK_FWD, 0, c->st);
+    ps_.name("mlp_l0_kernel");
+    if (!g_dry) {
+      BNN_TRY(set_lds(mlp_l0_kernel, ML0_LDS));
+      mlp_l0_kernel<<<dim3((unsigned)A.cg.nwin * 4), dim3(256), ML0_LDS, c->st>>>(A, M);
+    }
+  }
+  {
+    ProfScope ps_(&p->prof, PK_FWD, 1, c->st);
+    ps_.name("mlp_l14_kernel");
+    if (!g_dry) {
+      BNN_TRY(set_lds(mlp_l14_kernel, ML14_LDS));
+      mlp_l14_kernel<<<dim3((unsigned)A.cg.nwin), dim3(512), ML14_LDS, c->st>>>(A, M);
+    }
+  }
+  if (!g_dry) HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_mlp_bwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
+  GroupArgs A;
+  fill_group_args(p, a, c, 0, a->x, &A);
+  static thread_local MlpPlan M;
+  fill_mlp_plan(p, &M);
+  {
+    // the gradient images of this call are zeroed by the dX kernel (the dW kernel adds into them)
+    const size_t gwb = (size_t)c->S * p->img_total * 4, gbb = (size_t)c->S * p->bias_total * 4;
+    float* zp[4] = {ws_f(p, p->o_gw_a), ws_f(p, p->o_gw_b), ws_f(p, p->o_gb_a), ws_f(p, p->o_gb_b)};
+    const size_t zb[4] = {gwb, gwb, gbb, gbb};
+    for (int k = 0; k < 4; ++k) {
+      M.zero_p[k] = zp[k];
+      M.zero_n[k] = (long)((zb[k] + 15) / 16);   // regions are 256-byte aligned and padded
+    }
+  }
+  M.fuse_head = c->head_fused ? 1 : 0;
+  if (c->head_fused) {
+    M.head = HeadArgs{};
+    M.head.z = tens_ptr(p, p->z_t, 0);
+    M.head.y = a->y;
+    M.head.dz = nullptr;
+    M.head.preds = c->head_preds;
+    M.head.ll_acc = (double*)((char*)p->bufs.workspace + p->o_acc) + (p->d.max_particles + 1);
+    M.head.S = c->S;
+    M.head.B = c->B;
+    M.head.with_obs = a->with_obs && a->y;
+    M.head.objective = c->objective;
+  }
+  {
+    ProfScope ps_(&p->prof, PK_DX, 1, c->st);
+    ps_.name("mlp_dx_kernel");
+    if (!g_dry) {
+      BNN_TRY(set_lds(mlp_dx_kernel, MX_LDS));
+      mlp_dx_kernel<<<dim3((unsigned)A.cg.nwin), dim3(512), MX_LDS, c->st>>>(A, M);
+    }
+  }
+  static thread_local MlpDwPlan D;
+  D = MlpDwPlan{};
+  for (int l = 0; l < 5; ++l) {
+    const LayerDesc& ly = p->layers[l];
+    const int K = ly.KP;
+    for (int n0 = 0; n0 < ly.cout; n0 += 64)
+      for (int c0 = 0; c0 < K; c0 += 128) {
+        if (D.njobs >= 30) return fail(BNN_E_INVALID, "fused Linear net: dW job table");
+        MlpDwJob& J = D.job[D.njobs++];
+        if (l == 0) {
+          J.x = M.xhi + c0; J.x_ctot = ML_K0; J.x_bcast = 1;
+        } else {
+          J.x = (const u16*)M.h[l - 1].p + c0; J.x_ctot = M.h[l - 1].ctot; J.x_bcast = 0;
+        }
+        if (l < 4) {
+          J.dz = (const u16*)M.g[l].p + n0; J.dz2 = (const u16*)M.q[l].p + n0; J.z_ctot = M.g[l].ctot;
+        } else {
+          J.dz = M.dz4; J.dz2 = M.dz4 + M.dz4_plane; J.z_ctot = 8;
+        }
+        J.gwa = A.gw_a + ly.w_off + (long)n0 * ly.KP + c0;
+        J.gwb = A.gw_b + ly.w_off + (long)n0 * ly.KP + c0;
+        J.gba = c0 == 0 ? A.gb_a + ly.bias_off + n0 : nullptr;
+        J.gbb = c0 == 0 ? A.gb_b + ly.bias_off + n0 : nullptr;
+        J.cw = std::min(128, K - c0);
+        J.cout = std::min(64, ly.cout - n0);
+        J.KP = ly.KP;
+        if ((J.cw & 15) || (J.x_ctot & 7) || (J.z_ctot & 7)) return fail(BNN_E_INVALID, "fused Linear net: dW job shape");
+      }
+  }
+  D.nsplit = std::max(1, std::min(A.cg.nwin, 128 / std::max(1, D.njobs)));
+  static_assert(MW_AHEAD * 8 <= 49 && MW_RING >= MW_AHEAD + 2, "counted-wait range / ring");
+  {
+    ProfScope ps_(&p->prof, PK_DW, 0, c->st);
+    ps_.name("mlp_dw_kernel");
+    if (!g_dry) {
+      BNN_TRY(set_lds(mlp_dw_kernel, MW_LDS));
+      mlp_dw_kernel<<<dim3((unsigned)(D.njobs * D.nsplit)), dim3(MW_WAVES * 64), MW_LDS, c->st>>>(A.cg, D);
+    }
+  }
+  if (!g_dry) HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // fused conv trunk (kernels_trunk.h): groups 0..2 of the Inception net in one launch
 static bool trunk_ok(const BnnPlan* p, const Ctx* c) {
   return p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION && c->em != EM_LRT;
@@ -1546,6 +1681,12 @@ static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
   const bool trunk = trunk_ok(p, c);
+  if (mlp_ok(p, c)) {
+    BNN_TRY(launch_mlp_fwd(p, a, c, x));
+    p->last_S = c->S;
+    p->last_B = c->B;
+    return 0;
+  }
   if (trunk) BNN_TRY(launch_trunk_fwd(p, a, c, x));
   if (bf && p->d.net == BNN_NET_INCEPTION && !trunk) {
     const long rows = (long)c->B * p->d.win_length;
@@ -1596,6 +1737,7 @@ static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c);
 
 static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   const size_t gwb = (size_t)c->S * p->img_total * 4, gbb = (size_t)c->S * p->bias_total * 4;
+  if (mlp_ok(p, c)) return launch_mlp_bwd(p, a, c);   // zeroes the gradient images itself
   if (g_dry) {
   } else if (c->S == p->d.max_particles) {
     // gw_a | gw_b | gb_a | gb_b are back to back in the workspace: one fill
@@ -1701,7 +1843,9 @@ static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c) {
   return 0;
 }
 
-static int do_finalize(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
+static void fill_loss_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElboOut* out, bool to_grad, LossArgs* L);
+
+static int do_finalize(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElboOut* fused_out = nullptr, bool fuse_loss = false) {
   FinalizeArgs F{};
   F.T = p->ptab;
   F.layers = (const LayerDesc*)((char*)p->bufs.workspace + p->o_layers);
@@ -1723,6 +1867,11 @@ static int do_finalize(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   F.prior_loc = (float)a->prior_loc;
   F.prior_scale = (float)a->prior_scale;
   F.grad = p->bufs.grad;
+  if (fuse_loss) {
+    fill_loss_args(p, a, c, fused_out, true, &F.loss);
+    F.fused_loss = 1;
+    p->acc_clean = true;
+  }
   ProfScope ps_(&p->prof, PK_FINALIZE, 0, c->st);
   grad_finalize_kernel<<<dim3((unsigned)((p->P + 255) / 256)), dim3(256), 0, c->st>>>(F);
   HIP_TRY(hipGetLastError());
@@ -1731,7 +1880,18 @@ static int do_finalize(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
 
 static int do_loss(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElboOut* out, bool to_grad) {
   LossArgs LA{};
+  fill_loss_args(p, a, c, out, to_grad, &LA);
+  finish_loss_kernel<<<dim3(1), dim3(64), 0, c->st>>>(LA);
+  HIP_TRY(hipGetLastError());
+  p->acc_clean = true;
+  return 0;
+}
+
+static void fill_loss_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElboOut* out, bool to_grad, LossArgs* L) {
+  LossArgs& LA = *L;
+  LA = LossArgs{};
   double* acc = (double*)((char*)p->bufs.workspace + p->o_acc);
+  LA.n_acc = 2 * (p->d.max_particles + 1);
   LA.kl_acc = acc;
   LA.ll_acc = acc + (p->d.max_particles + 1);
   LA.S = c->S;
@@ -1744,9 +1904,6 @@ static int do_loss(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElbo
   LA.kl = (out && out->kl) ? out->kl : scal + 1;
   LA.ll = (out && out->loglik) ? out->loglik : scal + 2;
   LA.grad_tail = to_grad ? p->bufs.grad + 2 * p->P : nullptr;
-  finish_loss_kernel<<<dim3(1), dim3(64), 0, c->st>>>(LA);
-  HIP_TRY(hipGetLastError());
-  return 0;
 }
 
 static int do_adam(BnnPlan* p, const BnnAdamArgs* ad, hipStream_t st) {
@@ -1860,10 +2017,11 @@ extern "C" int bnn_elbo_step(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* n
   BNN_TRY(prepare_noise(p, a, nz, &c));
   BNN_TRY(do_sample(p, a, &c));
   BNN_TRY(do_forward(p, a, &c, a->x));
-  BNN_TRY(do_head(p, a, &c, out ? out->preds : nullptr, true));
+  c.head_fused = mlp_ok(p, &c);
+  c.head_preds = out ? out->preds : nullptr;
+  if (!c.head_fused) BNN_TRY(do_head(p, a, &c, c.head_preds, true));
   BNN_TRY(do_backward(p, a, &c));
-  BNN_TRY(do_finalize(p, a, &c));
-  BNN_TRY(do_loss(p, a, &c, out, true));
+  BNN_TRY(do_finalize(p, a, &c, out, true));   // + the loss scalars (one launch less)
   if (adam) BNN_TRY(do_adam(p, adam, c.st));
   return 0;
 }

@@ -60,6 +60,8 @@ class InjectedNoise:
 
 
 class SviEngine:
+    RESULT_SLOTS = 256   # ring of (loss, kl, loglik) result slots of step(): see its docstring
+
     def __init__(self, net: str = "inception", guide: str = "normal", fit_context: Optional[str] = "lrt",
                  prec: str = "bf16x3", max_particles: int = 1, max_batch: int = 100, win_length: int = 30,
                  n_features: int = 18, device: str | torch.device = "cuda:0", max_windows: int = 0):
@@ -109,6 +111,9 @@ class SviEngine:
             base = self._ws.data_ptr()
             self._ws_ptr = (base + 255) // 256 * 256
             self._scal = torch.zeros(4, dtype=torch.float32, device=dev)
+            # results of step(): a ring of slots, so that returning (loss, kl, loglik) costs no copy kernel
+            self._res_ring = torch.zeros(self.RESULT_SLOTS, 4, dtype=torch.float32, device=dev)
+            self._res_k = 0
             bufs = N.Buffers(self.mu.data_ptr(), self.rho.data_ptr(), self.adam_m.data_ptr(), self.adam_v.data_ptr(),
                              self.grad.data_ptr(), self._ws_ptr, self.workspace_bytes)
             N.check(self.lib.bnn_plan_bind(self._plan, C.byref(bufs)))
@@ -253,20 +258,25 @@ class SviEngine:
     def step(self, x: torch.Tensor, y: torch.Tensor, particles: int, dataset_size: float, prior_loc: float,
              prior_scale: float, adam: Optional[AdamHyper], noise: Optional[InjectedNoise] = None, seed: int = 0,
              step: Optional[int] = None, want_preds: bool = False, global_batch: int = 0,
-             global_batch_offset: int = 0):
+             global_batch_offset: int = 0, keep: bool = False):
         """svi.step (A4).  Returns (loss, kl, loglik) as a 3-element device tensor (no host
         sync) and optionally preds [S,B,2].  With ``adam=None`` the gradient is left in
-        ``self.grad`` for the DP all-reduce (see parallel.py) and no update is applied."""
+        ``self.grad`` for the DP all-reduce (see parallel.py) and no update is applied.
+        The result is a VIEW of one of ``RESULT_SLOTS`` ring slots: it stays valid for the next RESULT_SLOTS - 1 steps
+        (read or ``.item()`` it before that; ``keep=True`` returns a private copy at the price of a copy kernel)."""
         with torch.cuda.device(self.device):
             a = self._elbo_args(x, y, particles, dataset_size, prior_loc, prior_scale, None, 1, 1,
                                 global_batch_offset, global_batch)
             nz = self._noise(noise, seed, self.t if step is None else step)
             preds = torch.empty(particles, x.shape[0], 2, dtype=torch.float32, device=self.device) if want_preds else None
-            out = N.ElboOut(self._scal.data_ptr(), self._scal.data_ptr() + 4, self._scal.data_ptr() + 8, N.ptr(preds))
+            slot = self._res_ring[self._res_k]
+            self._res_k = (self._res_k + 1) % self.RESULT_SLOTS
+            sp = slot.data_ptr()
+            out = N.ElboOut(sp, sp + 4, sp + 8, N.ptr(preds))
             ad = self._adam_args(adam, 1.0) if adam is not None else None
             N.check(self.lib.bnn_elbo_step(self._plan, C.byref(a), C.byref(nz), C.byref(ad) if ad else None,
                                            C.byref(out), C.c_void_p(self._stream())))
-            res = self._scal[:3].clone()
+            res = slot[:3].clone() if keep else slot[:3]
         return (res, preds) if want_preds else res
 
     def det_step(self, x: torch.Tensor, y: torch.Tensor, objective: str, adam: Optional[AdamHyper],

@@ -157,7 +157,7 @@ class BNN(_Base):
         if prog is not None:
             prog.increment_ready()
         res, preds = self.engine.step(x, y, S, hp.dataset_size, hp.prior_loc, hp.prior_scale, self.adam,
-                                      seed=hp.seed, want_preds=True)
+                                      seed=hp.seed, want_preds=True, keep=True)   # logged per epoch: a private copy
         if prog is not None:
             prog.increment_completed()
         elbo, kl = res[0], res[1]

@@ -16,7 +16,7 @@ import json, subprocess, sys, os
 sys.path.insert(0, '.')
 import bayesrul_amd._native as N
 N.LIB_PATH = '/tmp/abl/lib_$v.so'
-sys.argv = ['bench.py', '--steps', '20', '--warmup', '3', '--no-cpu-baseline', '--no-companions']
+sys.argv = ['bench.py', '--steps', '50', '--warmup', '3', '--no-cpu-baseline', '--no-companions', '--workload', os.environ.get('ABL_WL', 'flipout_conv_s10')]
 import io, contextlib, runpy
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
@@ -25,6 +25,7 @@ for line in buf.getvalue().splitlines():
     if line.startswith('{'):
         d = json.loads(line)
         k = d['kernel_ms_per_step']
+        if os.environ.get('ABL_WL'): print('$v', 'ms', round(d['ms_per_step'], 4), k)
         print('$v', 'ms', round(d['ms_per_step'], 3), 'fwd0', k.get('fwd[0]'), 'dx1', k.get('dx[1]'), 'dw', k.get('dw[0]'), k.get('dw[1]'), k.get('dw[2]'), 'fwd3', k.get('fwd[3]'), 'dx3', k.get('dx[3]'))
 PY
 done
