@@ -22,6 +22,7 @@ struct ConvDwPlan {
   int zoff[BNN_MAX_BRANCH];
   int nsplit;             // workgroups per particle
   int has_pool;
+  int no_bias;            // 1: this launch covers part of the group's tiles and another launch sums the bias gradients
   DwTile tile[96];
 };
 
@@ -1240,7 +1241,7 @@ __global__ __launch_bounds__(NWV * 64) void conv_dw_mw_kernel(const GroupArgs A,
       if constexpr (DUAL) atomicAdd(gwb + o, acc_b[m][r]);
     }
   }
-  if ((lane & 15) == 0) {
+  if ((lane & 15) == 0 && !D.no_bias) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int zt = wave + CV_WAVES * q;

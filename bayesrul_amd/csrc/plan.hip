@@ -947,17 +947,11 @@ static int build_conv_fwd2_jobs(const GroupArgs& A, const LayerDesc* layers, uns
 
 template <int NC, int NL>
 static int launch_conv_fwd_dma_t(const GroupArgs& A, const ConvFwd2Plan& F, int em, int lds, unsigned grid, hipStream_t st) {
+  // the per-group conv kernels are the LRT path of the Inception net: every other estimator runs the fused trunk kernels
+  if (em != EM_LRT) return fail(BNN_E_INVALID, "per-group conv forward: estimator %d is covered by the trunk kernels", em);
   BNN_DRY_RETURN();
-  if (em == EM_PLAIN) {
-    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_PLAIN, NC, NL>, lds));
-    conv_fwd_dma_kernel<EM_PLAIN, NC, NL><<<dim3(grid), dim3((NC + NL) * 64), lds, st>>>(A, F);
-  } else if (em == EM_LRT) {
-    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_LRT, NC, NL>, lds));
-    conv_fwd_dma_kernel<EM_LRT, NC, NL><<<dim3(grid), dim3((NC + NL) * 64), lds, st>>>(A, F);
-  } else {
-    BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_FLIPOUT, NC, NL>, lds));
-    conv_fwd_dma_kernel<EM_FLIPOUT, NC, NL><<<dim3(grid), dim3((NC + NL) * 64), lds, st>>>(A, F);
-  }
+  BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_LRT, NC, NL>, lds));
+  conv_fwd_dma_kernel<EM_LRT, NC, NL><<<dim3(grid), dim3((NC + NL) * 64), lds, st>>>(A, F);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1041,26 +1035,21 @@ static void build_conv_dw_plan(const GroupArgs& A, const LayerDesc* layers, Conv
   D->zw = zo;
 }
 
-template <int EM, int NWI>
-static int launch_conv_dw_mw_em(const GroupArgs& A, const ConvDwPlan& D, int lds, unsigned grid, int nwv, hipStream_t st) {
+// The per-group conv dW kernel is the LRT path of the Inception net (the trunk kernels cover the other estimators).
+// Instantiations: <EM_LRT, 4 or 6 tiles per wave, 1 window per iteration, 8 waves> - the ones that fit the register file
+// (-Rpass-analysis=kernel-resource-usage: 0 bytes of scratch).  A group with more than 48 tiles is launched twice over
+// halves of its tile list; the second launch skips the bias sums.
+static int launch_conv_dw_mw_lrt(const GroupArgs& A, const ConvDwPlan& D, int lds, unsigned grid, hipStream_t st) {
   BNN_DRY_RETURN();
-  const int tpw = (D.ntiles + nwv - 1) / nwv;
-  if (nwv == 16) {   // 16-wave workgroups: at most 6 tiles per wave, one window per iteration
-    if constexpr (NWI == 1) {
-      BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 6, 1, 16>, lds));
-      conv_dw_mw_kernel<EM, 6, 1, 16><<<dim3(grid), dim3(1024), lds, st>>>(A, D);
-    } else {
-      return fail(BNN_E_INVALID, "conv dW: 16-wave variant is single-window");
-    }
-  } else if (tpw <= 4) {
-    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 4, NWI, 8>, lds));
-    conv_dw_mw_kernel<EM, 4, NWI, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+  const int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
+  if (tpw <= 4) {
+    BNN_TRY(set_lds(conv_dw_mw_kernel<EM_LRT, 4, 1, 8>, lds));
+    conv_dw_mw_kernel<EM_LRT, 4, 1, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
   } else if (tpw <= 6) {
-    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 6, NWI, 8>, lds));
-    conv_dw_mw_kernel<EM, 6, NWI, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+    BNN_TRY(set_lds(conv_dw_mw_kernel<EM_LRT, 6, 1, 8>, lds));
+    conv_dw_mw_kernel<EM_LRT, 6, 1, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
   } else {
-    BNN_TRY(set_lds(conv_dw_mw_kernel<EM, 11, NWI, 8>, lds));
-    conv_dw_mw_kernel<EM, 11, NWI, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
+    return fail(BNN_E_INVALID, "conv dW: %d tiles per wave", tpw);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1068,9 +1057,10 @@ static int launch_conv_dw_mw_em(const GroupArgs& A, const ConvDwPlan& D, int lds
 
 static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
-  ConvDwPlan D;
+  if (em != EM_LRT) return fail(BNN_E_INVALID, "per-group conv dW: estimator %d is covered by the trunk kernels", em);
+  static thread_local ConvDwPlan D, H;
   build_conv_dw_plan(A, layers, &D);
-  if (D.ntiles > 96 || (D.ntiles + CV_WAVES - 1) / CV_WAVES > 11) return fail(BNN_E_INVALID, "conv dW plan too large");
+  if (D.ntiles > 96) return fail(BNN_E_INVALID, "conv dW plan too large");
   if (A.g.in_cin_p % 8 || D.zw % 8) return fail(BNN_E_INVALID, "conv dW: channel counts must be multiples of 8");
   if (A.g.L * (A.g.in_cin_p / 8) > CV_THREADS || A.g.L * (D.zw / 8) > 2 * CV_THREADS)
     return fail(BNN_E_INVALID, "conv dW staging plan exceeds the compiled unit counts");
@@ -1078,32 +1068,23 @@ static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int e
   const int xw16 = rup(A.g.in_cin_p, 16);
   const int xbytes = (IMG_ROWS * img_row_stride(xw16, true) * 2 + 15) & ~15;
   const int zbytes = (IMG_ROWS * img_row_stride(D.zw, true) * 2 + 15) & ~15;
-  const bool lrt = em == EM_LRT;
-  const int wbytes = xbytes + (D.has_pool ? xbytes : 0) + zbytes + (lrt ? xbytes + (D.has_pool ? xbytes : 0) + zbytes : 0) +
-                     (em == EM_FLIPOUT ? 128 : 0);
-  // windows per iteration: bounded by LDS and by the registers that hold an iteration's loads
-  // (variants that would spill are avoided: measured with -Rpass-analysis)
-  int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
-  // more than 6 tiles per wave: 16-wave workgroups (<= 6 tiles each), one window per iteration with the next
-  // window's loads in flight
-  // (plain contraction only: the Flipout / LRT variants of that shape need more than the 128 registers of a
-  // 16-wave workgroup)
-  int nwv = (tpw > 6 && em == EM_PLAIN) ? 16 : 8;
-  if (nwv == 16) tpw = (D.ntiles + 15) / 16;
-  int nwi = lrt ? (tpw > 6 ? 1 : 2) : (nwv == 16 || tpw > 6 ? 1 : (em == EM_FLIPOUT ? 2 : 4));
-  while (nwi > 1 && nwi * wbytes > 160 * 1024) nwi /= 2;
-  if (nwi * wbytes > 160 * 1024) return fail(BNN_E_INVALID, "conv dW: %d bytes of LDS per window", wbytes);
-  const int lds = nwi * wbytes;
+  const int wbytes = 2 * (xbytes + (D.has_pool ? xbytes : 0) + zbytes);
+  if (wbytes > 160 * 1024) return fail(BNN_E_INVALID, "conv dW: %d bytes of LDS per window", wbytes);
+  const int lds = wbytes;
   const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
+  const int parts = D.ntiles > 6 * CV_WAVES ? 2 : 1;
   ProfScope ps_(pf, PK_DW, gi, st);
-  ps_.name("conv_dw_mw_kernel<%d, %d, %d, %d>", em, nwv == 16 ? 6 : (tpw <= 4 ? 4 : (tpw <= 6 ? 6 : 11)), nwi, nwv);
-#define DISPATCH_NWI(EMV)                                                                 \
-  (nwi == 4 ? launch_conv_dw_mw_em<EMV, 4>(A, D, lds, grid, nwv, st)                      \
-            : (nwi == 2 ? launch_conv_dw_mw_em<EMV, 2>(A, D, lds, grid, nwv, st) : launch_conv_dw_mw_em<EMV, 1>(A, D, lds, grid, nwv, st)))
-  if (em == EM_PLAIN) return DISPATCH_NWI(EM_PLAIN);
-  if (em == EM_LRT) return DISPATCH_NWI(EM_LRT);
-  return DISPATCH_NWI(EM_FLIPOUT);
-#undef DISPATCH_NWI
+  ps_.name("conv_dw_mw_kernel<1, %d, 1, 8>%s", (D.ntiles / parts + CV_WAVES - 1) / CV_WAVES <= 4 ? 4 : 6, parts == 2 ? " x2" : "");
+  if (parts == 1) return launch_conv_dw_mw_lrt(A, D, lds, grid, st);
+  const int half = (D.ntiles + 1) / 2;
+  for (int part = 0; part < 2; ++part) {
+    H = D;
+    H.ntiles = part == 0 ? half : D.ntiles - half;
+    for (int t = 0; t < H.ntiles; ++t) H.tile[t] = D.tile[part * half + t];
+    H.no_bias = part;
+    BNN_TRY(launch_conv_dw_mw_lrt(A, H, lds, grid, st));
+  }
+  return 0;
 }
 
 static int launch_dense_dw_bf(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
@@ -1247,14 +1228,9 @@ static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em,
       conv_dx2_kernel<EMV, 5, KPV, 4><<<dim3(grid), dim3(nw * 64), lds, st>>>(A, D);           \
     }                                                                                          \
   } while (0)
+  if (em != EM_LRT) return fail(BNN_E_INVALID, "per-group conv dX: estimator %d is covered by the trunk kernels", em);
   BNN_DRY_RETURN();
-  if (em == EM_PLAIN) {
-    if (nkp) LAUNCH_DX2(EM_PLAIN, 1); else LAUNCH_DX2(EM_PLAIN, 0);
-  } else if (em == EM_LRT) {
-    if (nkp) LAUNCH_DX2(EM_LRT, 1); else LAUNCH_DX2(EM_LRT, 0);
-  } else {
-    if (nkp) LAUNCH_DX2(EM_FLIPOUT, 1); else LAUNCH_DX2(EM_FLIPOUT, 0);
-  }
+  if (nkp) LAUNCH_DX2(EM_LRT, 1); else LAUNCH_DX2(EM_LRT, 0);
 #undef LAUNCH_DX2
   HIP_TRY(hipGetLastError());
   return 0;
