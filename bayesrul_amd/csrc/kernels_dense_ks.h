@@ -235,7 +235,9 @@ __global__ __launch_bounds__(DK_NW * 64) void dense_ks_fwd_kernel(const GroupArg
   }
 }
 
-// out = relu(bias + sum_chunk slab): one thread per (row, 4 channels), chunks summed in order (reproducible)
+// out = relu(bias + sum_chunk slab): one thread per (row, 4 channels), chunks summed in order (reproducible).
+// FUSE2: the net's last layer Linear(64, 2) (inception.py:217) is evaluated here as well - its input row is in the 16
+// lanes' registers - instead of in a launch of its own: z = W2 h + b2 (+ Flipout: s_out o (dW2 (h o s_in))).
 struct DenseKsFinArgs {
   const float* slab;
   long slab_stride;
@@ -246,12 +248,28 @@ struct DenseKsFinArgs {
   int relu;
   TensorRef out;
   int out_off;
+  // last layer (fuse2)
+  int fuse2;
+  const u16* w2_hi; const u16* w2_lo; const u16* w2_b;   // images of the last layer, offset to its first row
+  long w2_stride_a, w2_stride_b;                          // elements between particles (0: shared)
+  int w2_KP;
+  const float* b2;      // bias of the last layer [S or 1][bias_stride], offset to it
+  const uint32_t* sg_in; const uint32_t* sg_out;           // its Flipout sign words [rows][siw] / [rows][sow]
+  int siw, sow;
+  float* z;             // [rows][2]
+  // the last layer's gradient elements, zeroed here for the head launch's atomics: per particle 2 rows of KP in the
+  // weight images (slots A and B) and 2 biases
+  float* g2_a; float* g2_b; float* g2_ba;
+  long g2_stride; int g2_bstride;
+  int S;
 };
 
+template <int EM>
 __global__ __launch_bounds__(256) void dense_ks_fin_kernel(const DenseKsFinArgs F) {
+  constexpr bool FO = (EM == EM_FLIPOUT);
   const int t = blockIdx.x * 256 + threadIdx.x;
-  const int row = t >> 4, ch = (t & 15) * 4;
-  if (row >= F.rows) return;
+  const int row = min(t >> 4, F.rows - 1), ch = (t & 15) * 4;   // surplus threads redo the last row (the shuffles need full groups)
+  const bool live = (t >> 4) < F.rows;
   const int s = row / F.B;
   f32x4 v = *(const f32x4*)(F.bias + (long)F.bias_stride * s + ch);
   const float* p = F.slab + (long)row * 64 + ch;
@@ -264,7 +282,166 @@ __global__ __launch_bounds__(256) void dense_ks_fin_kernel(const DenseKsFinArgs 
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
   }
-  tstore4(F.out, (long)row * F.out.ctot + F.out_off + ch, v, 4, true);
+  if (live) tstore4(F.out, (long)row * F.out.ctot + F.out_off + ch, v, 4, true);
+  if (!F.fuse2) return;
+  if (t < F.S * 2 * F.w2_KP) {
+    const int zs = t / (2 * F.w2_KP), ze = t - zs * 2 * F.w2_KP;
+    F.g2_a[F.g2_stride * zs + ze] = 0.f;
+    F.g2_b[F.g2_stride * zs + ze] = 0.f;
+    if (ze < 2) F.g2_ba[(long)F.g2_bstride * zs + ze] = 0.f;
+  }
+  uint2 hv, lv;
+  split4(v, hv, lv);
+  const f32x4 xb = unpack_bf4(hv);   // what the perturbation path sees (single bf16)
+  const f32x4 xm = unpack_bf4(lv);
+  float m[2] = {0.f, 0.f}, pz[2] = {0.f, 0.f};
+  uint32_t bits = 0;
+  if constexpr (FO) bits = F.sg_in[(long)row * F.siw + (ch >> 5)] >> (ch & 31);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long wo = (long)k * F.w2_KP + ch;
+    const f32x4 wh = unpack_bf4(*(const uint2*)(F.w2_hi + F.w2_stride_a * s + wo));
+    const f32x4 wl = unpack_bf4(*(const uint2*)(F.w2_lo + F.w2_stride_a * s + wo));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[k] += (xb[r] + xm[r]) * (wh[r] + wl[r]);   // x = hi + lo, w = hi + lo
+    if constexpr (FO) {
+      const f32x4 wb = unpack_bf4(*(const uint2*)(F.w2_b + F.w2_stride_b * s + wo));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pz[k] += (((bits >> r) & 1u) ? -xb[r] : xb[r]) * wb[r];
+    }
+  }
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      m[k] += __shfl_xor(m[k], d, 16);
+      if constexpr (FO) pz[k] += __shfl_xor(pz[k], d, 16);
+    }
+  }
+  if (live && (t & 15) == 0) {
+    uint32_t so = 0;
+    if constexpr (FO) so = F.sg_out[(long)row * F.sow];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float zk = m[k] + F.b2[(long)F.bias_stride * s + k];
+      if constexpr (FO) zk += ((so >> k) & 1u) ? -pz[k] : pz[k];
+      F.z[(long)row * 2 + k] = zk;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// head + backward of the net's last layer Linear(64, 2) in one launch (the Inception net's training step): per example row
+// the head's d(-ll)/dz, then dH = dz W2 (+ Flipout: s_in o ((dz o s_out) dW2)) written as the bf16 gradient plane of H, and
+// per workgroup the layer's weight / bias gradient sums over its rows (fp32 atomics into the zeroed per-particle images).
+// Replaces head_nll_kernel + the layer's dX and dW launches.
+// ------------------------------------------------------------------------------------------
+struct HeadLastArgs {
+  HeadArgs H;
+  const u16* w_hi; const u16* w_b;      // forward images of the layer (bf16 hi of W | dW), offset to its first row
+  long stride_a, stride_b;              // elements between particles (0: shared)
+  int KP;
+  const u16* h_hi; int h_ctot;          // the layer's input, hi plane [S*B][64]
+  u16* dh; int dh_ctot;                 // gradient plane of H
+  const uint32_t* sg_in; const uint32_t* sg_out;
+  int siw, sow;
+  float* gw_a; float* gw_b; float* gb_a;   // offset to the layer; per particle strides below
+  long gw_stride; int gb_stride;
+};
+
+enum { HL_ROWS = 64 };   // example rows per workgroup
+
+template <int EM>
+__global__ __launch_bounds__(256) void head_last_kernel(const HeadLastArgs A) {
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  const int tid = threadIdx.x;
+  const int blk0 = blockIdx.x * HL_ROWS;
+  const int idx = blk0 + tid;   // rows: threads 0 .. HL_ROWS-1
+  const int s = blockIdx.y;
+  const int B = A.H.B;
+  __shared__ float dzs[4][HL_ROWS];
+  if (tid < HL_ROWS) {
+    double ll = 0.0;
+    float g0 = 0.f, g1 = 0.f;
+    if (idx < B) ll = head_row(A.H, s, idx, g0, g1);
+    ll = wave_sum_d(ll);   // HL_ROWS = one wave
+    if (tid == 0 && A.H.with_obs) atomicAdd(A.H.ll_acc + s, ll);
+    const long r = (long)s * B + min(idx, B - 1);
+    uint32_t so = 0;
+    if constexpr (FO) so = A.sg_out[r * A.sow];
+    const float h0 = (so & 1u) ? -g0 : g0, h1 = (so & 2u) ? -g1 : g1;   // dz o s_out
+    dzs[0][tid] = g0;
+    dzs[1][tid] = g1;
+    dzs[2][tid] = h0;
+    dzs[3][tid] = h1;
+    if (idx < B) {
+      const u16* w = A.w_hi + A.stride_a * s;
+      const u16* wb = A.w_b + A.stride_b * s;
+      uint32_t si[2] = {0u, 0u};
+      if constexpr (FO) {
+        si[0] = A.sg_in[r * A.siw];
+        si[1] = A.sg_in[r * A.siw + 1];
+      }
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) {
+        const uint4 w0 = *(const uint4*)(w + c8 * 8), w1 = *(const uint4*)(w + A.KP + c8 * 8);
+        const f32x4 a0 = unpack_bf4(make_uint2(w0.x, w0.y)), a1 = unpack_bf4(make_uint2(w0.z, w0.w));
+        const f32x4 b0 = unpack_bf4(make_uint2(w1.x, w1.y)), b1 = unpack_bf4(make_uint2(w1.z, w1.w));
+        f32x4 d0, d1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          d0[q] = g0 * a0[q] + g1 * b0[q];
+          d1[q] = g0 * a1[q] + g1 * b1[q];
+        }
+        if constexpr (FO) {
+          const uint4 v0 = *(const uint4*)(wb + c8 * 8), v1 = *(const uint4*)(wb + A.KP + c8 * 8);
+          const f32x4 e0 = unpack_bf4(make_uint2(v0.x, v0.y)), e1 = unpack_bf4(make_uint2(v0.z, v0.w));
+          const f32x4 f0 = unpack_bf4(make_uint2(v1.x, v1.y)), f1 = unpack_bf4(make_uint2(v1.z, v1.w));
+          const uint32_t byte = (si[c8 >> 2] >> ((c8 & 3) * 8)) & 0xffu;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float p0 = h0 * e0[q] + h1 * f0[q], p1 = h0 * e1[q] + h1 * f1[q];
+            d0[q] += ((byte >> q) & 1u) ? -p0 : p0;
+            d1[q] += ((byte >> (4 + q)) & 1u) ? -p1 : p1;
+          }
+        }
+        *(uint4*)(A.dh + r * A.dh_ctot + c8 * 8) =
+            make_uint4(cvt_pk(d0[0], d0[1]), cvt_pk(d0[2], d0[3]), cvt_pk(d1[0], d1[1]), cvt_pk(d1[2], d1[3]));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- weight / bias gradient sums of this workgroup's rows: thread = (kind kk, channel c) ----
+  const int kk = tid >> 6, c = tid & 63;   // kk 0, 1: d/dW_a rows 0, 1; kk 2, 3: d/dW_b rows 0, 1 (Flipout)
+  const int nrow = min(HL_ROWS, B - blk0);
+  if (kk < 2 || FO) {
+    float acc = 0.f;
+    const u16* hp = A.h_hi + ((long)s * B + blk0) * A.h_ctot + c;
+    const uint32_t* sp = A.sg_in + ((long)s * B + blk0) * A.siw + (c >> 5);
+    for (int r0 = 0; r0 < HL_ROWS; r0 += 16) {   // 16 rows of loads in flight
+      u16 hv[16];
+      uint32_t sw[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int rr = min(r0 + j, nrow - 1);
+        hv[j] = hp[(long)rr * A.h_ctot];
+        sw[j] = (FO && kk >= 2) ? sp[(long)rr * A.siw] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float h = bf2f(hv[j]);
+        if ((sw[j] >> (c & 31)) & 1u) h = -h;
+        if (r0 + j < nrow) acc += dzs[kk][r0 + j] * h;
+      }
+    }
+    float* g = (kk < 2 ? A.gw_a : A.gw_b) + A.gw_stride * s + (long)(kk & 1) * A.KP + c;
+    atomicAdd(g, acc);
+  }
+  if (tid < 2) {   // bias gradient: sum of dz (Flipout's arrives through slot A only)
+    float acc = 0.f;
+    for (int rr = 0; rr < nrow; ++rr) acc += dzs[tid][rr];
+    atomicAdd(A.gb_a + (long)A.gb_stride * s + tid, acc);
+  }
 }
 
 // ==========================================================================================

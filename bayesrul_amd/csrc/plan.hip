@@ -136,6 +136,7 @@ struct BnnPlan {
   size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
   size_t o_dks = 0;                                // partial pre-activations of the K-split dense forward [chunk][rows][64]
   long dks_rows = 0;
+  bool fwd_fused_last = false;                     // the last do_forward evaluated the last layer in the fin kernel (and zeroed its gradients)
   bool acc_clean = false;                          // the loss accumulators are zero (the last finish_loss re-armed them)
   size_t o_mlp_x = 0, o_mlp_dz4 = 0;               // fused Linear-net kernels: x hi plane [B][544]; dz / dz q of the last layer
   int mlp = 0;
@@ -591,6 +592,8 @@ struct Ctx {
   int objective = 0;   // 0 ELBO; 1 / 2: frequentist objectives (bnn_det_step)
   NoiseRefs nz{};
   int s_base = 0;  // particle offset for noise streams (predict chunks)
+  bool grads_zeroed = false;     // the gradient images need no fill in do_backward (done earlier, or every element is stored)
+  bool last_fused = false;       // Inception trunk path: the last layer Linear(64, 2) runs inside the fin / head kernels
   bool head_fused = false;       // bnn_elbo_step on the fused Linear-net path: the head runs inside the backward's first kernel
   float* head_preds = nullptr;
 };
@@ -1282,7 +1285,18 @@ static bool dense_ks_ok(const BnnPlan* p, const GroupArgs& A, int em) {
          (size_t)A.cg.S * A.cg.B * A.t[A.g.in_t].ctot * 2 < ((size_t)1 << 32);
 }
 
-static int launch_dense_ks_fwd(BnnPlan* p, const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
+// the last layer Linear(64, 2) of the Inception net can ride on the K-split dense kernels' fin / head launches
+static bool last_fused_ok(const BnnPlan* p, int em, int gi) {
+  if (em == EM_LRT || p->o_dks == 0 || gi + 2 != p->n_groups) return false;
+  const GroupDesc& g = p->groups[gi + 1];
+  const BranchDesc& br = g.br[0];
+  const LayerDesc& ly = p->layers[br.layer];
+  return g.is_dense && g.n_branch == 1 && br.cout == 2 && br.cin_p == 64 && br.n_off == 0 && br.in_off == 0 && !br.relu &&
+         ly.KP == 64 && g.in_t == p->groups[gi].br[0].out_t && p->groups[gi].br[0].out_off == 0 && br.out_t == p->z_t &&
+         p->tens[g.in_t].ctot == 64 && ly.sign_in_words == 2 && ly.sign_out_words == 1;
+}
+
+static int launch_dense_ks_fwd(BnnPlan* p, const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last) {
   GroupArgs A = A0;
   const BranchDesc& br = A.g.br[0];
   const LayerDesc& ly = p->layers[br.layer];
@@ -1319,7 +1333,31 @@ static int launch_dense_ks_fwd(BnnPlan* p, const GroupArgs& A0, int em, hipStrea
   R.relu = br.relu;
   R.out = A.t[br.out_t];
   R.out_off = br.out_off;
-  dense_ks_fin_kernel<<<dim3((unsigned)((R.rows * 16 + 255) / 256)), dim3(256), 0, st>>>(R);
+  if (fuse_last) {
+    const LayerDesc& l2 = p->layers[p->groups[gi + 1].br[0].layer];
+    R.fuse2 = 1;
+    R.w2_hi = (const u16*)A.ws.a_hi + l2.w_off;
+    R.w2_lo = (const u16*)A.ws.a_lo + l2.w_off;
+    R.w2_b = (const u16*)A.ws.b + l2.w_off;
+    R.w2_stride_a = A.ws.slot_stride_a;
+    R.w2_stride_b = A.ws.slot_stride_b;
+    R.w2_KP = l2.KP;
+    R.b2 = A.ws.bias_a + l2.bias_off;
+    R.sg_in = A.nz.sign_in + l2.sign_in_off * A.nz.examples;
+    R.sg_out = A.nz.sign_out + l2.sign_out_off * A.nz.examples;
+    R.siw = l2.sign_in_words;
+    R.sow = l2.sign_out_words;
+    R.z = tens_ptr(p, p->z_t, 0);
+    R.g2_a = A.gw_a + l2.w_off;
+    R.g2_b = A.gw_b + l2.w_off;
+    R.g2_ba = A.gb_a + l2.bias_off;
+    R.g2_stride = A.gw_stride;
+    R.g2_bstride = A.gb_stride;
+    R.S = A.cg.S;
+  }
+  const unsigned fgrid = (unsigned)((R.rows * 16 + 255) / 256);
+  if (em == EM_PLAIN) dense_ks_fin_kernel<EM_PLAIN><<<dim3(fgrid), dim3(256), 0, st>>>(R);
+  else dense_ks_fin_kernel<EM_FLIPOUT><<<dim3(fgrid), dim3(256), 0, st>>>(R);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1657,6 +1695,7 @@ static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
   const bool trunk = trunk_ok(p, c);
+  p->fwd_fused_last = false;
   if (mlp_ok(p, c)) {
     BNN_TRY(launch_mlp_fwd(p, a, c, x));
     p->last_S = c->S;
@@ -1680,8 +1719,12 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
       BNN_TRY(launch_conv_fwd_dma(A, p->layers, c->em, c->st, &p->prof, gi));
-    else if (dense_ks_ok(p, A, c->em))
-      BNN_TRY(launch_dense_ks_fwd(p, A, c->em, c->st, &p->prof, gi));
+    else if (dense_ks_ok(p, A, c->em)) {
+      const bool fl = last_fused_ok(p, c->em, gi);
+      BNN_TRY(launch_dense_ks_fwd(p, A, c->em, c->st, &p->prof, gi, fl));
+      p->fwd_fused_last = fl;
+      if (fl) ++gi;   // the last layer was evaluated by the fin kernel
+    }
     else if (dense_dma_ok(A))
       BNN_TRY(launch_dense_fwd2(A, c->em, c->st, &p->prof, gi));
     else
@@ -1704,6 +1747,42 @@ static int do_head(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, float* preds,
   H.with_obs = a->with_obs && a->y;
   H.objective = c->objective;
   ProfScope ps_(&p->prof, PK_HEAD, 0, c->st);
+  if (c->last_fused && want_dz) {
+    // head + backward of the last layer in one launch (its gradient images were zeroed by do_backward's fill, which
+    // therefore runs BEFORE the head on this path: see bnn_elbo_step)
+    ps_.name("head_last_kernel<%d>", c->em);
+    GroupArgs A;
+    fill_group_args(p, a, c, p->n_groups - 1, a->x, &A);
+    const BranchDesc& br = A.g.br[0];
+    const LayerDesc& ly = p->layers[br.layer];
+    HeadLastArgs L{};
+    L.H = H;
+    L.H.dz = nullptr;
+    L.w_hi = (const u16*)A.ws.a_hi + ly.w_off;
+    L.w_b = (const u16*)A.ws.b + ly.w_off;
+    L.stride_a = A.ws.slot_stride_a;
+    L.stride_b = A.ws.slot_stride_b;
+    L.KP = ly.KP;
+    L.h_hi = (const u16*)A.t[A.g.in_t].p;
+    L.h_ctot = A.t[A.g.in_t].ctot;
+    L.dh = (u16*)A.t[br.dx_t].p;
+    L.dh_ctot = A.t[br.dx_t].ctot;
+    L.sg_in = A.nz.sign_in + ly.sign_in_off * A.nz.examples;
+    L.sg_out = A.nz.sign_out + ly.sign_out_off * A.nz.examples;
+    L.siw = ly.sign_in_words;
+    L.sow = ly.sign_out_words;
+    L.gw_a = A.gw_a + ly.w_off;
+    L.gw_b = A.gw_b + ly.w_off;
+    L.gb_a = A.gb_a + ly.bias_off;
+    L.gw_stride = A.gw_stride;
+    L.gb_stride = A.gb_stride;
+    if (g_dry) return 0;
+    const dim3 hgrid((unsigned)((c->B + HL_ROWS - 1) / HL_ROWS), (unsigned)c->S);
+    if (c->em == EM_PLAIN) head_last_kernel<EM_PLAIN><<<hgrid, dim3(256), 0, c->st>>>(L);
+    else head_last_kernel<EM_FLIPOUT><<<hgrid, dim3(256), 0, c->st>>>(L);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   head_nll_kernel<<<dim3((c->B + 255) / 256, c->S), dim3(256), 0, c->st>>>(H);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1711,9 +1790,8 @@ static int do_head(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, float* preds,
 
 static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c);
 
-static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
+static int zero_grad_images(BnnPlan* p, const Ctx* c) {
   const size_t gwb = (size_t)c->S * p->img_total * 4, gbb = (size_t)c->S * p->bias_total * 4;
-  if (mlp_ok(p, c)) return launch_mlp_bwd(p, a, c);   // zeroes the gradient images itself
   if (g_dry) {
   } else if (c->S == p->d.max_particles) {
     // gw_a | gw_b | gb_a | gb_b are back to back in the workspace: one fill
@@ -1724,7 +1802,27 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gb_a), 0, gbb, c->st));
     HIP_TRY(hipMemsetAsync(ws_f(p, p->o_gb_b), 0, gbb, c->st));
   }
-  for (int gi = p->n_groups - 1; gi >= 0; --gi) {
+  return 0;
+}
+
+// Training-step tail on the Inception trunk path: the last layer's backward rides on the head launch (its atomics need
+// zeroed images BEFORE the head), and when every other element of the gradient images is stored, not added (slabs for the
+// conv layers, one workgroup per (particle, chunk) for the wide dense layer), the fill is not needed at all: the fin
+// kernel of the forward zeroed the last layer's few elements.
+static int prepare_fused_tail(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
+  c->last_fused = trunk_ok(p, c) && p->fwd_fused_last && last_fused_ok(p, c->em, p->n_groups - 2);
+  if (!c->last_fused) return 0;
+  const BranchDesc& br = p->groups[p->n_groups - 2].br[0];
+  const bool direct = c->S * ((br.cin_p + DB_CH - 1) / DB_CH) >= 128;   // launch_dense_ks_bwd: nsplit == 1
+  if (!direct) BNN_TRY(zero_grad_images(p, c));
+  c->grads_zeroed = true;
+  return 0;
+}
+
+static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
+  if (mlp_ok(p, c)) return launch_mlp_bwd(p, a, c);   // zeroes the gradient images itself
+  if (!c->grads_zeroed) BNN_TRY(zero_grad_images(p, c));
+  for (int gi = p->n_groups - 1 - (c->last_fused ? 1 : 0); gi >= 0; --gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
     if (!A.g.is_dense && trunk_ok(p, c)) {
@@ -1995,6 +2093,7 @@ extern "C" int bnn_elbo_step(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* n
   BNN_TRY(do_forward(p, a, &c, a->x));
   c.head_fused = mlp_ok(p, &c);
   c.head_preds = out ? out->preds : nullptr;
+  BNN_TRY(prepare_fused_tail(p, a, &c));
   if (!c.head_fused) BNN_TRY(do_head(p, a, &c, c.head_preds, true));
   BNN_TRY(do_backward(p, a, &c));
   BNN_TRY(do_finalize(p, a, &c, out, true));   // + the loss scalars (one launch less)
@@ -2033,6 +2132,7 @@ extern "C" int bnn_det_step(BnnPlan* p, const BnnDetArgs* d, const BnnAdamArgs* 
   BNN_TRY(prepare_noise(p, &a, &nz, &c));
   BNN_TRY(do_sample(p, &a, &c));
   BNN_TRY(do_forward(p, &a, &c, a.x));
+  BNN_TRY(prepare_fused_tail(p, &a, &c));
   BNN_TRY(do_head(p, &a, &c, out ? out->preds : nullptr, true));
   BNN_TRY(do_backward(p, &a, &c));
   const float c_kl = c.c;
