@@ -529,7 +529,13 @@ struct SlabReduceArgs {
   int S;
 };
 
-__global__ void slab_reduce_kernel(const SlabReduceArgs A) {
+// the (up to) three reductions of a step - slot A, slot B, bias sums - in one launch: blockIdx.z picks the job
+struct SlabReduceJobs {
+  SlabReduceArgs job[3];
+};
+
+__global__ void slab_reduce_kernel(const SlabReduceJobs J) {
+  const SlabReduceArgs& A = J.job[blockIdx.z];
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int s = blockIdx.y;
   if (e >= A.elems) return;

@@ -1898,9 +1898,13 @@ static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c) {
   if (g_dry) return 0;
   ProfScope ps_(&p->prof, PK_FINALIZE, 1, c->st);
   ps_.name("slab_reduce_kernel");
+  static thread_local SlabReduceJobs J;
+  int nj = 0;
+  long max_elems = 0;
   for (int which = 0; which < 3; ++which) {   // 0: slot A, 1: slot B (Flipout's dW part), 2: bias sums
     if (which == 1 && c->em != EM_FLIPOUT) continue;
-    SlabReduceArgs R{};
+    SlabReduceArgs& R = J.job[nj++];
+    R = SlabReduceArgs{};
     for (int g = 0; g < 3; ++g) {
       R.slab[g] = ws_f(p, which == 0 ? p->o_slab_a[g] : (which == 1 ? p->o_slab_b[g] : p->o_slab_ba[g]));
       R.n[g] = trunk_dw_nsplit(c, g);
@@ -1911,8 +1915,9 @@ static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c) {
     R.out = ws_f(p, which == 0 ? p->o_gw_a : (which == 1 ? p->o_gw_b : p->o_gb_a));
     R.out_stride = which == 2 ? p->bias_total : p->img_total;
     R.S = c->S;
-    slab_reduce_kernel<<<dim3((unsigned)((R.elems + 255) / 256), c->S), dim3(256), 0, c->st>>>(R);
+    max_elems = std::max(max_elems, R.elems);
   }
+  slab_reduce_kernel<<<dim3((unsigned)((max_elems + 255) / 256), c->S, nj), dim3(256), 0, c->st>>>(J);
   HIP_TRY(hipGetLastError());
   return 0;
 }
