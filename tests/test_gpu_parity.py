@@ -277,6 +277,33 @@ def test_full_size_properties():
     assert abs(float(a[1] - b[1])) <= 1e-6 * abs(float(a[1]))
     P = R.n_params("inception")
     assert rel_l2(out["bf16x3"][1][:P], out["f32"][1][:P]) < 3e-2
+    assert rel_l2(out["bf16x3"][1][P:2 * P], out["f32"][1][P:2 * P]) < 8e-2   # d/d rho (single-bf16 backward)
+
+
+def test_dp_step_world1_equals_plain_step():
+    """`parallel.dp_step` (what `bench.py --gpus N` runs per rank: local step with adam=None -> all-reduce of grad[2P+2]
+    -> ClippedAdam with grad_scale) with world = 1 is the plain `eng.step(adam=hyp)`: parameters, Adam moments, the step
+    counter and the decayed lr agree bit for bit over three steps, and the returned (loss, kl) come from the gradient
+    buffer's tail."""
+    from bayesrul_amd.engine import AdamHyper
+    from bayesrul_amd.parallel import dp_step
+    S, B = 2, 64
+    ps, qs, lr = HYP["flipout"]
+    x, y = synth_batch(B)
+    xg, yg = x.cuda(), y.cuda()
+    mu0 = R.init_mu0("inception", 0, torch.float64)
+    hyp = AdamHyper(lr=lr, betas=(0.95, 0.999), clip_norm=15.0)
+    ea = _engine("inception", "flipout", "bf16x3", S, B)
+    eb = _engine("inception", "flipout", "bf16x3", S, B)
+    ea.init_params(mu0, qs)
+    eb.init_params(mu0, qs)
+    for k in range(3):
+        ra = ea.step(xg, yg, S, N_DATA, 0.0, ps, hyp, seed=3, keep=True)
+        rb = dp_step(eb, xg, yg, S, N_DATA, 0.0, ps, hyp, rank=0, world=1, seed=3)
+        assert torch.equal(ra[:2].cpu(), rb[:2].cpu()), (k, ra, rb)
+        assert ea.t == eb.t and ea.lr == eb.lr
+    assert torch.equal(ea.mu, eb.mu) and torch.equal(ea.rho, eb.rho)
+    assert torch.equal(ea.adam_m, eb.adam_m) and torch.equal(ea.adam_v, eb.adam_v)
 
 
 def test_dp_noise_is_rank_invariant():
