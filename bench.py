@@ -355,7 +355,10 @@ def main():
             step_traffic = 0.0
             for r in csv.DictReader(open(pmc)):
                 b = (2 * float(r["FETCH_SIZE_KB_per_launch"]) + float(r["WRITE_SIZE_KB_per_launch"])) * 1024
-                step_traffic += b * float(r.get("launches_per_step", 1) or 1)
+                lps = float(r.get("launches_per_step", 1) or 1)
+                if "fillBuffer" in r["kernel"] and lps < 1.0:
+                    continue   # the one-off zero fill of the workspace at bind time, not step traffic
+                step_traffic += b * lps
                 if sym in r["kernel"]:
                     traffic = b
         alg_bytes = algorithmic_bytes_per_step(wl["net"], S, B, predict)
