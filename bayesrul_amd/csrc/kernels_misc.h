@@ -94,9 +94,25 @@ struct SignGenArgs {
   int words[2 * BNN_MAX_LAYERS];
   int layer[2 * BNN_MAX_LAYERS];
   uint32_t kind[2 * BNN_MAX_LAYERS];
+  // optional extra entry blockIdx.y == n: the weight noise eps_w[S][P] of the same step (one launch less)
+  float* eps;
+  long P;
+  uint64_t eps_seed;
 };
 __global__ void gen_signs_all_kernel(const SignGenArgs A) {
   const int e = blockIdx.y;
+  if (e == A.n) {   // gen_eps_w_kernel's work
+    const long n4 = (A.P + 3) >> 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n4 * A.S) return;
+    const int s = (int)(idx / n4);
+    const long q = idx - (long)s * n4;
+    const f32x4 z = philox_normal4((uint32_t)q, (uint32_t)s, NK_EPSW, A.step, A.eps_seed);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (q * 4 + r < A.P) A.eps[(long)s * A.P + q * 4 + r] = z[r];
+    return;
+  }
   const int words = A.words[e];
   const int w4 = (words + 3) >> 2;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,11 +275,26 @@ __global__ void prep_weights_kernel(const PrepArgs A) {
     }
   }
   if (A.mode != 1) {
-    for (int s = 0; s < A.S; ++s) {
+    // the particles' noise values of this element: loads of four particles in flight (a load per iteration followed by
+    // its dependent stores made the kernel latency-bound: S round trips per thread)
+    for (int s0 = 0; s0 < A.S; s0 += 4) {
+      float ev[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = min(s0 + u, A.S - 1);
+        if (live) {
+          ev[u] = A.eps_w[(long)s * A.T.P + e];
+          if (radial) rv[u] = A.rad_r[s * A.T.n_sites + si] / A.norms[s * A.T.n_sites + si];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u;
+      if (s >= A.S) break;
       double term = 0.0;
       if (live) {
-        float eps = A.eps_w[(long)s * A.T.P + e];
-        if (radial) eps = eps * (A.rad_r[s * A.T.n_sites + si] / A.norms[s * A.T.n_sites + si]);
+        float eps = ev[u];
+        if (radial) eps = eps * rv[u];
         const float dw = sigma * eps;
         const float w = mu + dw;
         if (is_bias) {
@@ -290,6 +321,7 @@ __global__ void prep_weights_kernel(const PrepArgs A) {
           if (s < RS_MAX) atomicAdd(&red_s[s], t);
           else atomicAdd(A.kl_acc + s, t);
         }
+      }
       }
     }
     if (radial) {
@@ -475,6 +507,7 @@ __global__ void grad_finalize_kernel(const FinalizeArgs A) {
     drho = A.scale_ll * sb * 2.f * sigma * sigma;
   } else if (A.mode == 2) {  // flipout: mean path shared, perturbation dW_s = sigma*eps_s
     float sa = 0.f, sb = 0.f;
+#pragma unroll 4
     for (int s = 0; s < A.S; ++s) {
       const float eps = A.eps_w[(long)s * A.T.P + e];
       const float a = ga[gs * s + gi];
@@ -486,6 +519,7 @@ __global__ void grad_finalize_kernel(const FinalizeArgs A) {
     drho = A.scale_ll * sb * sigma;
   } else if (A.mode == 0) {  // plain normal sampling
     float sa = 0.f, sb = 0.f;
+#pragma unroll 4
     for (int s = 0; s < A.S; ++s) {
       const float a = ga[gs * s + gi];
       sa += a;
@@ -495,6 +529,7 @@ __global__ void grad_finalize_kernel(const FinalizeArgs A) {
     drho = A.scale_ll * sb * sigma;
   } else {  // radial + Trace_ELBO: pathwise through w, log p(w); d log q/d rho = -1
     const float cs = A.c / (float)A.S;
+#pragma unroll 4
     for (int s = 0; s < A.S; ++s) {
       const float er = A.eps_w[(long)s * A.T.P + e] * (A.rad_r[s * A.T.n_sites + si] / A.norms[s * A.T.n_sites + si]);
       const float w = mu + sigma * er;
