@@ -21,6 +21,9 @@
 #ifndef TR_ABL
 #define TR_ABL 0
 #endif
+#ifndef TR_SWAP
+#define TR_SWAP 0
+#endif
 #include "kernels_conv_bf.h"
 #include "kernels_conv_dx.h"   // rot16
 
@@ -144,7 +147,7 @@ struct TrunkJobRun {
     constexpr int chb0 = NT * 16;
     // one accumulator: out = bias + W_mu x  (+ Flipout: (s_out o dW o s_in) x, both signs folded into the dW fragment)
     f32x4 acc[2];
-    acc[0] = acc[1] = bias;
+    if constexpr (TR_ABL & 2) acc[0] = acc[1] = bias;
     uint32_t rs8 = 0;
     if constexpr (FO) rs8 = ((sg[4 + (chb0 >> 5)] >> ((chb0 & 31) + i16)) & 1u) << 8;   // s_out of this lane's fragment row
 #pragma unroll
@@ -165,7 +168,8 @@ struct TrunkJobRun {
         const int off = (mt * 16 + tap - PAD + HALO) * RS + (tl_inch(LY) + c0) * 16;
         const bf16x8 bh = *(const bf16x8*)(lb + off);
         const bf16x8 bl = *(const bf16x8*)(lb + PLANE + off);
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, acc[mt], 0, 0, 0);
+        // the first MFMA of a tile takes the bias registers as its C operand (no copy of the bias into the accumulator)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bh, ks == 0 ? bias : acc[mt], 0, 0, 0);
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], bl, acc[mt], 0, 0, 0);
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlk, bh, acc[mt], 0, 0, 0);
         if constexpr (FO) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbm, bh, acc[mt], 0, 0, 0);
@@ -404,20 +408,26 @@ __global__ __launch_bounds__(TR_THREADS) void trunk_fwd_kernel(const TrunkArgs A
   // jobs: (layer, n-tile).  Dealt by cost (MFMAs + epilogue, the block-1 epilogue pools) so that every wave, and the
   // three waves that share a SIMD (w, w+4, w+8), carry about the same work per step.
 #define TR_ROLE(...) trunk_role<EM, TRAIN, __VA_ARGS__>(A, smem, s, split, nwin, lane)
+  // TR_SWAP (diagnostics): bit w = wave w runs its two jobs in the other order (the order inside a step is free: every
+  // job reads images of earlier steps and writes images of later ones)
+#define TR_ROLE2(W, JA, JB) do { if constexpr ((TR_SWAP >> (W)) & 1) TR_ROLE(JB, JA, TNone); else TR_ROLE(JA, JB, TNone); } while (0)
+#define TJ(...) TJob<__VA_ARGS__>
   switch (wave) {
     case 0: TR_ROLE(TJob<8, 0, true>, TNone, TNone); break;          // k5 64->16 (10 k-steps)
-    case 4: TR_ROLE(TJob<5, 0>, TJob<1, 0>, TNone); break;
-    case 8: TR_ROLE(TJob<5, 1>, TJob<5, 2>, TNone); break;
-    case 1: TR_ROLE(TJob<6, 0>, TJob<0, 0>, TNone); break;           // k3 64->16 (6 k-steps) + block-1 k1
-    case 5: TR_ROLE(TJob<5, 3>, TJob<1, 1>, TNone); break;
-    case 9: TR_ROLE(TJob<7, 0>, TJob<7, 1>, TNone); break;
-    case 2: TR_ROLE(TJob<2, 0>, TJob<4, 0>, TNone); break;           // block-1 k5 (5 k-steps) + a 1x1 tile
-    case 6: TR_ROLE(TJob<7, 2>, TJob<3, 0>, TNone); break;
-    case 10: TR_ROLE(TJob<7, 3>, TJob<0, 1>, TNone); break;
-    case 3: TR_ROLE(TJob<2, 1>, TJob<9, 0>, TNone); break;
-    case 7: TR_ROLE(TJob<9, 1>, TJob<3, 1>, TNone); break;
+    case 4: TR_ROLE2(4, TJ(5, 0), TJ(1, 0)); break;
+    case 8: TR_ROLE2(8, TJ(5, 1), TJ(5, 2)); break;
+    case 1: TR_ROLE2(1, TJ(6, 0), TJ(0, 0)); break;           // k3 64->16 (6 k-steps) + block-1 k1
+    case 5: TR_ROLE2(5, TJ(5, 3), TJ(1, 1)); break;
+    case 9: TR_ROLE2(9, TJ(7, 0), TJ(7, 1)); break;
+    case 2: TR_ROLE2(2, TJ(2, 0), TJ(4, 0)); break;           // block-1 k5 (5 k-steps) + a 1x1 tile
+    case 6: TR_ROLE2(6, TJ(7, 2), TJ(3, 0)); break;
+    case 10: TR_ROLE2(10, TJ(7, 3), TJ(0, 1)); break;
+    case 3: TR_ROLE2(3, TJ(2, 1), TJ(9, 0)); break;
+    case 7: TR_ROLE2(7, TJ(9, 1), TJ(3, 1)); break;
     default: trunk_loader<EM>(A, smem, s, split, nwin, lane); break;
   }
+#undef TJ
+#undef TR_ROLE2
 #undef TR_ROLE
 }
 

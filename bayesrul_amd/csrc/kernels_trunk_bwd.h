@@ -55,12 +55,13 @@ struct TrunkDxArgs {
   int S, B, L, nsplit;
 };
 
-// Y is a ReLU output (never negative): Y > 0  <=>  magnitude bits non-zero; packed 16-bit min / mul
+// Y is a ReLU output (never negative): Y > 0  <=>  magnitude bits non-zero.  Packed 16-bit min / mul through inline asm:
+// hipcc turns the vector-extension form into v_cmp_ne_u16 + v_cndmask pairs (7 instructions per dword instead of 3)
 __device__ __forceinline__ uint32_t relu_mask2(uint32_t yy) {
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  const us2 v = __builtin_bit_cast(us2, yy & 0x7fff7fffu);
-  const us2 m = __builtin_elementwise_min(v, us2{1, 1}) * us2{0xffff, 0xffff};
-  return __builtin_bit_cast(uint32_t, m);
+  uint32_t m = yy & 0x7fff7fffu;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(0x00010001u));
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(0xffffffffu));
+  return m;
 }
 
 template <int EM>
