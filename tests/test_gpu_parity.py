@@ -237,9 +237,10 @@ def test_ragged_and_single_window_batches():
 @pytest.mark.parametrize("mode", ["lrt", "flipout", "radial"])
 def test_ragged_batches_bf16x3(mode):
     """The role-specialised bf16x3 kernels on awkward geometries: one window, a dense chunk of 32 + 1, more
-    window sets than windows per particle, a partial last dense window - ELBO within the north star's 1e-3
-    (held: 2e-4) and gradients within the single-bf16 backward tolerance."""
-    for S, B in ((1, 1), (3, 33), (2, 257)):
+    window sets than windows per particle, a partial last dense window, and enough particles for the store-only dense dW
+    path (one workgroup per (particle, chunk), no gradient-image fill) with a ragged window - ELBO within the north star's
+    1e-3 (held: 2e-4) and gradients within the single-bf16 backward tolerance."""
+    for S, B in ((1, 1), (3, 33), (2, 257), (8, 41)):
         eng, cfg, st, x, y, noise, (ps, qs, lr) = _setup("inception", mode, "bf16x3", S, B)
         inj = to_injected(eng, cfg, noise, B)
         res = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, noise=inj)
