@@ -33,6 +33,8 @@ struct DenseKsPlan {
   int nsplit;         // window splits per (particle, chunk)
   float* slab;        // forward: [nchunk][rows][64] partial pre-activations
   long slab_stride;   // rows * 64
+  int mask_x;         // backward: the layer's input is a ReLU output - store dX already masked with [X > 0] (the X chunk is
+                      // in LDS anyway), so that the consumer neither reads X again nor rewrites the gradient
   LayerDesc ly;       // the layer's table entry BY VALUE: a kernel argument (scalar registers), not a global load.  A
                       // vector load in the common prologue stays "pending" in hipcc's vmcnt bookkeeping of every role
                       // that does not use it, and turns into vmcnt(N) waits in front of the loaders' unmodelled DMAs
@@ -714,6 +716,13 @@ __global__ __launch_bounds__(DB_WAVES * 64) void dense_ks_bwd_kernel(const Group
             const uint32_t bits = sg[row * 4 + (t >> 1)] >> ((t & 1) * 16 + 4 * g4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += ((bits >> r) & 1u) ? -acc_b[mt][r] : acc_b[mt][r];
+          }
+          if (F.mask_x) {
+            const int ch = t * 16 + 4 * g4;
+            const uint2 xv = *(const uint2*)(smem + DB_O_XR + ring * DB_IMG + row * 256 + (((ch >> 3) ^ f128(row)) << 4) + (ch & 7) * 2);
+            const f32x4 xf = unpack_bf4(xv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = xf[r] > 0.f ? v[r] : 0.f;
           }
           if (row < nv && !(DK_ABL & 128)) tstore4(tdx, (row0 + row) * tdx.ctot + br.in_off + chunk * DB_CH + t * 16 + 4 * g4, v, 4, true);
         }

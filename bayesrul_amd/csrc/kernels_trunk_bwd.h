@@ -64,7 +64,9 @@ __device__ __forceinline__ uint32_t relu_mask2(uint32_t yy) {
   return m;
 }
 
-template <int EM>
+// PRE: dY of ACT2 arrives already masked with [ACT2 > 0] (dense_ks_bwd_kernel stores it that way): the loaders neither read
+// ACT2 nor write the gradient back
+template <int EM, bool PRE>
 __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool FO = (EM == EM_FLIPOUT);
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
       setup(lane >> 3, lane & 7, sg0, sst0);
       if (lane < 16) setup(8 + (lane >> 3), lane & 7, sg1, sst1);
     }
-    uint4 g0, g1, g2, g3, g4_, y0, y1, y2, y3, y4;
+    uint4 g0, g1, g2, g3, g4_;
+    uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0, y2 = y0, y3 = y0, y4 = y0;
     uint32_t sb0 = 0, sb1 = 0;
     int qo[5];
 #pragma unroll
@@ -161,11 +164,14 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
   do {                                                                         \
     const char* gp = (const char*)A.g_act2 + (Rs + (K) * Rstep) * 160;         \
     const char* yp = (const char*)A.act2_hi + (Rs + (K) * Rstep) * 160;        \
-    g0 = *(const uint4*)(gp + qo[0]); y0 = *(const uint4*)(yp + qo[0]);        \
-    g1 = *(const uint4*)(gp + qo[1]); y1 = *(const uint4*)(yp + qo[1]);        \
-    g2 = *(const uint4*)(gp + qo[2]); y2 = *(const uint4*)(yp + qo[2]);        \
-    g3 = *(const uint4*)(gp + qo[3]); y3 = *(const uint4*)(yp + qo[3]);        \
-    g4_ = *(const uint4*)(gp + qo[4]); y4 = *(const uint4*)(yp + qo[4]);       \
+    g0 = *(const uint4*)(gp + qo[0]); g1 = *(const uint4*)(gp + qo[1]);        \
+    g2 = *(const uint4*)(gp + qo[2]); g3 = *(const uint4*)(gp + qo[3]);        \
+    g4_ = *(const uint4*)(gp + qo[4]);                                         \
+    if constexpr (!PRE) {                                                      \
+      y0 = *(const uint4*)(yp + qo[0]); y1 = *(const uint4*)(yp + qo[1]);      \
+      y2 = *(const uint4*)(yp + qo[2]); y3 = *(const uint4*)(yp + qo[3]);      \
+      y4 = *(const uint4*)(yp + qo[4]);                                        \
+    }                                                                          \
     if constexpr (FO) {                                                        \
       if (sg0) sb0 = sg0[(long)(K) * sst0];                                    \
       if (sg1) sb1 = sg1[(long)(K) * sst1];                                    \
@@ -185,10 +191,10 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         fm = lut[((widx < 64 ? w0 : w1) >> sh) & 0xffu];
       }
       if (q < n2) {
-        g.x &= relu_mask2(y.x); g.y &= relu_mask2(y.y); g.z &= relu_mask2(y.z); g.w &= relu_mask2(y.w);
+        if constexpr (!PRE) { g.x &= relu_mask2(y.x); g.y &= relu_mask2(y.y); g.z &= relu_mask2(y.z); g.w &= relu_mask2(y.w); }
         const int o = (row + HALO) * TX_RS2 + c * 16;
         *(uint4*)(sl + o) = g;
-        if constexpr (!(TX_ABL & 1)) *(uint4*)(gdst + q * 16) = g;   // the dW kernels read dz(ACT2) from HBM: masked once, here
+        if constexpr (!(TX_ABL & 1) && !PRE) *(uint4*)(gdst + q * 16) = g;   // the dW kernels read dz(ACT2) from HBM: masked once, here
         if constexpr (FO) *(uint4*)(sl + TX_P2 + o) = make_uint4(g.x ^ fm.x, g.y ^ fm.y, g.z ^ fm.z, g.w ^ fm.w);
       }
     };

@@ -1379,6 +1379,7 @@ static int launch_dense_ks_bwd(BnnPlan* p, const GroupArgs& A0, int em, hipStrea
   const int pairs = A.cg.S * F.nchunk;
   F.nsplit = pairs >= 128 ? 1 : std::min(A.cg.per_particle, (256 + pairs - 1) / pairs);
   F.ly = p->layers[br.layer];
+  F.mask_x = 1;   // the layer's input (ACT2) is the concatenation of ReLU outputs (inception.py:118-131)
   static_assert(DB_LDS <= 160 * 1024 && DB_WAVES <= 16, "one workgroup per CU");
   static_assert(DB_AHEAD * 10 <= 49 && DB_RING >= DB_AHEAD + 2, "counted-wait range / ring: windows k-1 .. k+4 are live");
   if ((br.cin_p & 15) || (A.t[br.dx_t].ctot & 3) || p->layers[br.layer].KPt < 64)
@@ -1665,7 +1666,7 @@ static int launch_trunk_dw2(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
 }
 
 // fused conv-trunk dX (kernels_trunk_bwd.h): dz of MID and of ACT1 from dY(ACT2), groups 2 and 1 in one launch
-static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
+static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, bool premasked) {
   GroupArgs G;
   fill_group_args(p, a, c, 1, a->x, &G);
   TrunkDxArgs T{};
@@ -1687,14 +1688,24 @@ static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   T.nsplit = std::max(1, std::min(c->B, 256 / std::max(1, c->S)));
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DX, 1, c->st);
-  ps_.name("trunk_dx_kernel<%d>", c->em);
+  ps_.name("trunk_dx_kernel<%d, %s>", c->em, premasked ? "true" : "false");
   BNN_DRY_RETURN();
   if (c->em == EM_FLIPOUT) {
-    BNN_TRY(set_lds(trunk_dx_kernel<EM_FLIPOUT>, TX_LDS));
-    trunk_dx_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TX_THREADS), TX_LDS, c->st>>>(T);
+    if (premasked) {
+      BNN_TRY(set_lds((trunk_dx_kernel<EM_FLIPOUT, true>), TX_LDS));
+      trunk_dx_kernel<EM_FLIPOUT, true><<<dim3(grid), dim3(TX_THREADS), TX_LDS, c->st>>>(T);
+    } else {
+      BNN_TRY(set_lds((trunk_dx_kernel<EM_FLIPOUT, false>), TX_LDS));
+      trunk_dx_kernel<EM_FLIPOUT, false><<<dim3(grid), dim3(TX_THREADS), TX_LDS, c->st>>>(T);
+    }
   } else {
-    BNN_TRY(set_lds(trunk_dx_kernel<EM_PLAIN>, TX_LDS));
-    trunk_dx_kernel<EM_PLAIN><<<dim3(grid), dim3(TX_THREADS), TX_LDS, c->st>>>(T);
+    if (premasked) {
+      BNN_TRY(set_lds((trunk_dx_kernel<EM_PLAIN, true>), TX_LDS));
+      trunk_dx_kernel<EM_PLAIN, true><<<dim3(grid), dim3(TX_THREADS), TX_LDS, c->st>>>(T);
+    } else {
+      BNN_TRY(set_lds((trunk_dx_kernel<EM_PLAIN, false>), TX_LDS));
+      trunk_dx_kernel<EM_PLAIN, false><<<dim3(grid), dim3(TX_THREADS), TX_LDS, c->st>>>(T);
+    }
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1830,13 +1841,14 @@ static int prepare_fused_tail(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
 static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   if (mlp_ok(p, c)) return launch_mlp_bwd(p, a, c);   // zeroes the gradient images itself
   if (!c->grads_zeroed) BNN_TRY(zero_grad_images(p, c));
+  bool act2_premasked = false;
   for (int gi = p->n_groups - 1 - (c->last_fused ? 1 : 0); gi >= 0; --gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
     if (!A.g.is_dense && trunk_ok(p, c)) {
       // conv trunk: dz of MID / ACT1 (and the masked dz of ACT2) first, then the three dW kernels
       if (gi == 2) {
-        BNN_TRY(launch_trunk_dx(p, a, c));
+        BNN_TRY(launch_trunk_dx(p, a, c, act2_premasked));
         BNN_TRY(launch_trunk_dw2(p, a, c, 1));
       } else if (gi == 1) {
         BNN_TRY(launch_trunk_dw2(p, a, c, 0));
@@ -1848,6 +1860,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     }
     if (A.g.is_dense && dense_ks_ok(p, A, c->em) && A.g.br[0].dx_t >= 0 && A.t[A.g.br[0].out_t].fmt == TF_BF16) {
       BNN_TRY(launch_dense_ks_bwd(p, A, c->em, c->st, &p->prof, gi));
+      act2_premasked = true;   // its dX is stored masked with [input > 0]
       continue;
     }
     if (p->d.prec == BNN_PREC_F32)
