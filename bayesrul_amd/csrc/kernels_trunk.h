@@ -72,7 +72,9 @@ struct TrunkArgs {
   u16* mid_hi;               // [S*B*L][128]
   u16* act2_hi;              // [S*B*L][80]
   u16* act2_lo;
-  unsigned char* amax;       // [S*B*L][128] arg-max codes of block 2's pooled branch (training step only)
+  unsigned char* amax;       // [S*B*L][32] 2-bit arg-max codes of block 2's pooled branch, 4 channels per byte (training step only)
+  unsigned char* m_act1;     // [S*B*L][16] bit masks [ACT1 > 0], 8 channels per byte (training step only): what the backward
+  unsigned char* m_mid;      // [S*B*L][16] needs of ACT1 / MID besides the dW operands
   int S, B, L, nsplit;
 };
 
@@ -230,7 +232,7 @@ struct TrunkJobRun {
           const float d = i16 == 15 ? dn1 : dn0;
           if (i16 + 1 < L && d > best) { best = d; c = 2u; }
           p[0][r] = best;
-          if constexpr (TRAIN) code[0] |= c << (8 * r);
+          if constexpr (TRAIN) code[0] |= c << (2 * r);
         }
         {   // m-tile 1: row = 16 + i16
           float best = a1;
@@ -239,7 +241,7 @@ struct TrunkJobRun {
           if (u >= best) { best = u; c = 0u; }
           if (17 + i16 < L && dn1 > best) { best = dn1; c = 2u; }
           p[1][r] = best;
-          if constexpr (TRAIN) code[1] |= c << (8 * r);
+          if constexpr (TRAIN) code[1] |= c << (2 * r);
         }
       }
 #pragma unroll
@@ -252,7 +254,7 @@ struct TrunkJobRun {
           const int o = (row + HALO) * TR_RSB + (OOFF + chb) * 2;
           *(uint2*)(img + o) = hv;
           *(uint2*)(img + TR_PA + o) = lv;
-          if constexpr (TRAIN && !(TR_ABL & 1)) *(uint32_t*)(A.amax + ((R0 + (unsigned)row) * 128u + (unsigned)(OOFF + chb))) = code[mt];
+          if constexpr (TRAIN && !(TR_ABL & 1)) A.amax[(R0 + (unsigned)row) * 32u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)code[mt];
         }
       }
     }
@@ -302,7 +304,33 @@ __device__ __forceinline__ void trunk_role(const TrunkArgs& A, char* smem, int s
 }
 
 // loader wave: x planes (and Flipout sign words) of the next windows, global -> registers -> LDS
-template <int EM>
+// bit mask [v > 0] of the 8 bf16 values of a 16-byte piece (ReLU outputs: > 0 <=> non-zero)
+__device__ __forceinline__ uint32_t tr_mask8(tr_u32x4 d) {
+  uint32_t b = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t t;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(d[i]), "v"(0x00010001u));
+    b |= ((t | (t >> 15)) & 3u) << (2 * i);
+  }
+  return b;
+}
+
+// mask plane rows of one window from its hi image in LDS: lane = (row, half of the 128 channels) -> 8 bytes
+__device__ __forceinline__ void trunk_mask_rows(const char* img, unsigned char* plane, unsigned R0, int L, int lane) {
+  const int row = lane >> 1, half = lane & 1;
+  if (row >= L) return;
+  const char* p = img + (row + HALO) * TR_RSB + half * 128;
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    lo |= tr_mask8(*(const tr_u32x4*)(p + j * 16)) << (8 * j);
+    hi |= tr_mask8(*(const tr_u32x4*)(p + (4 + j) * 16)) << (8 * j);
+  }
+  *(uint2*)(plane + (R0 + (unsigned)row) * 16u + (unsigned)(half * 8)) = make_uint2(lo, hi);
+}
+
+template <int EM, bool TRAIN>
 __device__ __forceinline__ void trunk_loader(const TrunkArgs& A, char* smem, int s, int split, int nwin, int lane) {
   constexpr bool FO = (EM == EM_FLIPOUT);
   const int L = A.L;
@@ -384,9 +412,16 @@ __device__ __forceinline__ void trunk_loader(const TrunkArgs& A, char* smem, int
   if (nwin > 1) TR_FETCH();
   lds_barrier();     // window 0 staged
   const int nsteps = nwin + 2;
+  const unsigned Rs = (unsigned)(((long)s * A.B + split) * A.L), Rstep = (unsigned)(A.nsplit * A.L);
   for (int t = 0; t < nsteps; ++t) {
     if (t + 1 < nwin) TR_PUT(t + 1);
     if (t + 2 < nwin) TR_FETCH();
+    if constexpr (TRAIN) {
+      // the backward's ReLU masks of ACT1 (window t-1: its image is complete and is being read by the 1x1 level) and of
+      // MID (window t-2), from the hi images in LDS: 16 bytes per row instead of the 256-byte hi rows the dX would re-read
+      if (t >= 1 && t - 1 < nwin) trunk_mask_rows(smem + TR_A1B + ((t - 1) & 1) * 4 * TR_PA, A.m_act1, Rs + (t - 1) * Rstep, L, lane);
+      if (t >= 2 && t - 2 < nwin) trunk_mask_rows(smem + TR_O_MID + ((t - 2) & 1) * 2 * TR_PB, A.m_mid, Rs + (t - 2) * Rstep, L, lane);
+    }
     lds_barrier();
   }
 #undef TR_FETCH
@@ -424,7 +459,7 @@ __global__ __launch_bounds__(TR_THREADS) void trunk_fwd_kernel(const TrunkArgs A
     case 10: TR_ROLE2(10, TJ(7, 3), TJ(0, 1)); break;
     case 3: TR_ROLE2(3, TJ(2, 1), TJ(9, 0)); break;
     case 7: TR_ROLE2(7, TJ(9, 1), TJ(3, 1)); break;
-    default: trunk_loader<EM>(A, smem, s, split, nwin, lane); break;
+    default: trunk_loader<EM, TRAIN>(A, smem, s, split, nwin, lane); break;
   }
 #undef TJ
 #undef TR_ROLE2

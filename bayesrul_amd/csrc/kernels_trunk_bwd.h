@@ -31,20 +31,21 @@ enum {
   TX_O_DZM = 3 * TX_SLOT,              // [2 bufs][dz(MID), dz(MID) o s_out]
   TX_O_SGN = TX_O_DZM + 2 * 2 * TX_PM, // [3 slots][80 words]
   TX_O_LUT = TX_O_SGN + 3 * 80 * 4,    // 256 x 16 B sign-byte -> XOR mask
-  // mask sources, LDS-DMA'd two steps ahead into a ring of 4: MID hi | ACT1 hi | arg-max codes (dense rows, 16-byte chunks
-  // XOR-swizzled by the row through the per-lane SOURCE address).  Not part of the zero fill: the DMA may land first.
-  TX_PD = 30 * 256, TX_PC = 30 * 128,
+  // mask sources, LDS-DMA'd two steps ahead into a ring of 4: bit masks [MID > 0] [32 rows][16 B] | [ACT1 > 0] [32][16 B] |
+  // 2-bit arg-max codes [32][32 B] (planes written by the forward).  Not part of the zero fill: the DMA may land first.
+  TX_PD = 512, TX_PC = 1024,
   TX_DSLOT = 2 * TX_PD + TX_PC,
   TX_O_DMA = TX_O_LUT + 4096,
-  TX_LDS = TX_O_DMA + 4 * TX_DSLOT
+  TX_O_MLUT = TX_O_DMA + 4 * TX_DSLOT,   // 16 x 8 B: mask nibble -> AND masks of 4 bf16 values
+  TX_LDS = TX_O_MLUT + 128
 };
 
 struct TrunkDxArgs {
   u16* g_act2;             // [S*B*L][80]  in: dY of ACT2 (from the dense layer's dX); out: masked with [ACT2 > 0] in place
   const u16* act2_hi;      // [S*B*L][80]
-  const u16* mid_hi;       // [S*B*L][128]
-  const u16* act1_hi;      // [S*B*L][128]
-  const unsigned char* amax;   // [S*B*L][128]
+  const unsigned char* m_mid;    // [S*B*L][16] bit masks [MID > 0]
+  const unsigned char* m_act1;   // [S*B*L][16] bit masks [ACT1 > 0]
+  const unsigned char* amax;     // [S*B*L][32] 2-bit arg-max codes
   u16* g_mid;              // [S*B*L][128]  out: dz of block 2's 1x1 outputs (masked)
   u16* g_act1;             // [S*B*L][128]  out: dz of block 1's outputs (masked)
   WeightSlots ws;
@@ -79,6 +80,9 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
     uint32_t* z = (uint32_t*)smem;
     for (int k = tid; k < TX_O_LUT / 4; k += TX_THREADS) z[k] = 0u;
     build_sign_lut((uint4*)(smem + TX_O_LUT), tid, TX_THREADS);
+    if (tid < 16)
+      *(uint2*)(smem + TX_O_MLUT + tid * 8) = make_uint2(((tid & 1) ? 0xffffu : 0u) | ((tid & 2) ? 0xffff0000u : 0u),
+                                                         ((tid & 4) ? 0xffffu : 0u) | ((tid & 8) ? 0xffff0000u : 0u));
   }
   const long Rs = ((long)s * A.B + split) * L, Rstep = (long)A.nsplit * L;
   const int nsteps = nwin + 1;
@@ -88,30 +92,23 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
     // =========================== LDS-DMA loader: mask sources ===========================
     // step t issues MID hi of window t+3 and ACT1 hi + codes of window t+2, then waits until only the DMAs of this step
     // and the previous one are in flight: what the stages read at step t+1 (MID hi of t+1, ACT1 hi / codes of t) landed.
-    const int nm = L * 16, nc = L * 8;
-    const int n_m = (nm + 63) >> 6, n_c = (nc + 63) >> 6;   // instructions per plane
+    // one instruction per plane: the window's rows are contiguous (L x 16 B masks, L x 32 B codes)
     const uint32_t lds0 = lds_addr(smem) + TX_O_DMA;
-    auto dma_plane = [&](const void* plane, long R0, int rowbytes, int lg, int n, int ninst, uint32_t dst) __attribute__((always_inline)) {
-      const int cm = (1 << lg) - 1;
-      for (int j = 0; j < ninst; ++j) {
-        const int q = j * 64 + lane;
-        const int row = q >> lg, pz = q & cm;
-        const int c = pz ^ (row & cm);
-        const char* src = (const char*)plane + (R0 + row) * rowbytes + c * 16;
-        if constexpr (!(TX_ABL & 4)) {
-          if (q < n) dma16(src, __builtin_amdgcn_readfirstlane(dst + (uint32_t)j * 1024u));
-        }
+    auto dma_rows = [&](const unsigned char* plane, long R0, int rowbytes, uint32_t dst) __attribute__((always_inline)) {
+      if constexpr (!(TX_ABL & 4)) {
+        if (lane * 16 < L * rowbytes) dma16(plane + R0 * rowbytes + lane * 16, __builtin_amdgcn_readfirstlane(dst));
       }
     };
     auto issue_mid = [&](int k) __attribute__((always_inline)) {
-      if (k < nwin) dma_plane(A.mid_hi, Rs + k * Rstep, 256, 4, nm, n_m, lds0 + (uint32_t)((k & 3) * TX_DSLOT));
+      if (k < nwin) dma_rows(A.m_mid, Rs + k * Rstep, 16, lds0 + (uint32_t)((k & 3) * TX_DSLOT));
     };
     auto issue_a1 = [&](int k) __attribute__((always_inline)) {
       if (k < nwin) {
-        dma_plane(A.act1_hi, Rs + k * Rstep, 256, 4, nm, n_m, lds0 + (uint32_t)((k & 3) * TX_DSLOT + TX_PD));
-        dma_plane(A.amax, Rs + k * Rstep, 128, 3, nc, n_c, lds0 + (uint32_t)((k & 3) * TX_DSLOT + 2 * TX_PD));
+        dma_rows(A.m_act1, Rs + k * Rstep, 16, lds0 + (uint32_t)((k & 3) * TX_DSLOT + TX_PD));
+        dma_rows(A.amax, Rs + k * Rstep, 32, lds0 + (uint32_t)((k & 3) * TX_DSLOT + 2 * TX_PD));
       }
     };
+    constexpr int n_m = 1, n_c = 1;
     const int per_mid = n_m, per_a1 = n_m + n_c;
     // in-flight bookkeeping: number of DMA instructions issued in the current and the previous step
     issue_mid(0); issue_a1(0); issue_mid(1); issue_a1(1); issue_mid(2);
@@ -321,10 +318,11 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
             for (int mt = 0; mt < 2; ++mt) {
               const int row = mt * 16 + i16;
               if (row < L) {
-                const uint2 y = *(const uint2*)(dsl + row * 256 + (((och >> 3) ^ (row & 15)) << 4) + (och & 7) * 2);
+                const uint32_t mb = *(const unsigned char*)(dsl + row * 16 + (och >> 3));
+                const uint2 mk = *(const uint2*)(smem + TX_O_MLUT + ((mb >> (och & 4)) & 15u) * 8);
                 uint2 d = pack_bf4(acc[mt]);
-                d.x &= relu_mask2(y.x);
-                d.y &= relu_mask2(y.y);
+                d.x &= mk.x;
+                d.y &= mk.y;
                 const int o = (row + HALO) * TR_RSB + och * 2;
                 *(uint2*)(dzm + o) = d;
                 if constexpr (FO) {
@@ -423,10 +421,10 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         for (int mt = 0; mt < 2; ++mt) {
           const int row = mt * 16 + i16;
           v[mt] = acc[mt];
-          const uint32_t code = row < L ? *(const uint32_t*)(dsl + 2 * TX_PD + row * 128 + (((och >> 4) ^ (row & 7)) << 4) + (och & 15)) : 0x01010101u;
+          const uint32_t code = row < L ? *(const unsigned char*)(dsl + 2 * TX_PD + row * 32 + (och >> 2)) : 0x55u;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const uint32_t cd = (code >> (8 * r)) & 3u;
+            const uint32_t cd = (code >> (2 * r)) & 3u;
             const float g = row < L ? accp[mt][r] : 0.f;
             v[mt][r] += cd == 1u ? g : 0.f;
             up[mt][r] = cd == 0u ? g : 0.f;
@@ -445,10 +443,11 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         for (int mt = 0; mt < 2; ++mt) {
           const int row = mt * 16 + i16;
           if (row < L) {
-            const uint2 y = *(const uint2*)(dsl + TX_PD + row * 256 + (((och >> 3) ^ (row & 15)) << 4) + (och & 7) * 2);
+            const uint32_t mb = *(const unsigned char*)(dsl + TX_PD + row * 16 + (och >> 3));
+            const uint2 mk = *(const uint2*)(smem + TX_O_MLUT + ((mb >> (och & 4)) & 15u) * 8);
             uint2 d = pack_bf4(v[mt]);
-            d.x &= relu_mask2(y.x);
-            d.y &= relu_mask2(y.y);
+            d.x &= mk.x;
+            d.y &= mk.y;
             if constexpr (!(TX_ABL & 1)) *(uint2*)((char*)A.g_act1 + ((R0 + (unsigned)row) * 256u + (unsigned)(och * 2))) = d;
             else asm volatile("" ::"v"(d.x), "v"(d.y));
           }

@@ -134,6 +134,7 @@ struct BnnPlan {
   // workspace layout (byte offsets)
   size_t ws_bytes = 0;
   size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
+  size_t o_mact1 = 0, o_mmid = 0;                  // bit masks [ACT1 > 0] / [MID > 0] of the trunk kernels: [rows][16 B]
   size_t o_dks = 0;                                // partial pre-activations of the K-split dense forward [chunk][rows][64]
   long dks_rows = 0;
   bool fwd_fused_last = false;                     // the last do_forward evaluated the last layer in the fin kernel (and zeroed its gradients)
@@ -415,6 +416,8 @@ static void layout_workspace(BnnPlan* p) {
     p->o_mlp_dz4 = take((size_t)cap * 8 * 2 * 2);
   }
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
+    p->o_mact1 = take((size_t)cap * p->d.win_length * 16);
+    p->o_mmid = take((size_t)cap * p->d.win_length * 16);
     p->dks_rows = cap;
     p->o_dks = take((size_t)((p->layers[10].cin + DK_CH - 1) / DK_CH) * cap * 64 * 4);
   }
@@ -1567,6 +1570,8 @@ static int launch_trunk_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, cons
   T.act2_hi = (u16*)a2.p;
   T.act2_lo = (u16*)a2.lo;
   T.amax = c->train ? (unsigned char*)p->bufs.workspace + p->o_amax : nullptr;
+  T.m_act1 = c->train ? (unsigned char*)p->bufs.workspace + p->o_mact1 : nullptr;
+  T.m_mid = c->train ? (unsigned char*)p->bufs.workspace + p->o_mmid : nullptr;
   T.S = c->S;
   T.B = c->B;
   T.L = L;
@@ -1672,9 +1677,9 @@ static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, bool 
   TrunkDxArgs T{};
   T.g_act2 = (u16*)tens_ref(p, TI_ACT2, 1).p;
   T.act2_hi = (const u16*)tens_ref(p, TI_ACT2, 0).p;
-  T.mid_hi = (const u16*)tens_ref(p, TI_MID, 0).p;
-  T.act1_hi = (const u16*)tens_ref(p, TI_ACT1, 0).p;
   T.amax = (const unsigned char*)p->bufs.workspace + p->o_amax;
+  T.m_act1 = (const unsigned char*)p->bufs.workspace + p->o_mact1;
+  T.m_mid = (const unsigned char*)p->bufs.workspace + p->o_mmid;
   T.g_mid = (u16*)tens_ref(p, TI_MID, 1).p;
   T.g_act1 = (u16*)tens_ref(p, TI_ACT1, 1).p;
   T.ws = G.ws;
