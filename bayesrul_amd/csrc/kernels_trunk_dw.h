@@ -516,10 +516,12 @@ __global__ __launch_bounds__(TW2A_THREADS) void trunk_dw2a_kernel(const TrunkDw2
           const int q = j * 64 + lane, qq = q < nz ? q : 0;
           b[j] = *(const tr_u32x4*)((const char*)A.g_mid + R0 * 256 + qq * 16);
         }
+        // dz(ACT2): only the channels of this kernel's layers (4: pieces 0, 1; 9: pieces 6 .. 9 of the row's 10)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const int q = j * 64 + lane, qq = q < n2 ? q : 0;
-          b[8 + j] = *(const tr_u32x4*)((const char*)A.g_act2 + R0 * 160 + qq * 16);
+        for (int j = 0; j < 3; ++j) {
+          const int q = j * 64 + lane, qq = q < L * 6 ? q : 0;
+          const int row = qq / 6, cc = qq - row * 6;
+          b[8 + j] = *(const tr_u32x4*)((const char*)A.g_act2 + (R0 + row) * 160 + (cc < 2 ? cc : cc + 4) * 16);
         }
         if constexpr (FO) {
           if (sgp) sw = sgp[(long)k * sgs];
@@ -534,10 +536,10 @@ __global__ __launch_bounds__(TW2A_THREADS) void trunk_dw2a_kernel(const TrunkDw2
           if (q < nz) *(tr_u32x4*)(sl + 2 * TW_PH + row * 256 + ((c ^ f128(row)) << 4)) = b[j];
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < 3; ++j) {
           const int q = j * 64 + lane;
-          const int row = q / 10, c = q - row * 10;
-          if (q < n2) *(tr_u32x4*)(sl + 2 * TW_PH + TW_PZ + row * 256 + ((c ^ f128(row)) << 4)) = b[8 + j];
+          const int row = q / 6, cc = q - row * 6, c = cc < 2 ? cc : cc + 4;
+          if (q < L * 6) *(tr_u32x4*)(sl + 2 * TW_PH + TW_PZ + row * 256 + ((c ^ f128(row)) << 4)) = b[8 + j];
         }
         if constexpr (FO) {
           if (lane < 48) ((uint32_t*)(smem + TW2A_O_SGN))[(k % 3) * 48 + lane] = sw;
@@ -593,10 +595,11 @@ __global__ __launch_bounds__(TW2B_THREADS) void trunk_dw2b_kernel(const TrunkDw2
         const int q = j * 64 + lane, qq = q < nz ? q : 0;
         b[j] = *(const tr_u32x4*)((const char*)A.x_hi + R0 * 256 + qq * 16);
       }
+      // dz(ACT2): only the channels of layers 6 and 8 (pieces 2 .. 5 of the row's 10)
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const int q = j * 64 + lane, qq = q < n2 ? q : 0;
-        b[8 + j] = *(const tr_u32x4*)((const char*)A.g_act2 + R0 * 160 + qq * 16);
+      for (int j = 0; j < 2; ++j) {
+        const int q = j * 64 + lane, qq = q < L * 4 ? q : 0;
+        b[8 + j] = *(const tr_u32x4*)((const char*)A.g_act2 + (R0 + (qq >> 2)) * 160 + (2 + (qq & 3)) * 16);
       }
       if constexpr (FO) {
         if (sgp) sw = sgp[(long)k * sgs];
@@ -613,10 +616,10 @@ __global__ __launch_bounds__(TW2B_THREADS) void trunk_dw2b_kernel(const TrunkDw2
         }
       }
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < 2; ++j) {
         const int q = j * 64 + lane;
-        if (q < n2) {
-          const int row = q / 10, c = q - row * 10;
+        if (q < L * 4) {
+          const int row = q >> 2, c = 2 + (q & 3);
           *(tr_u32x4*)(sl + TW_PH + row * 256 + ((c ^ f128(row)) << 4)) = b[8 + j];
         }
       }
