@@ -31,12 +31,12 @@ enum {
   TX_O_DZM = 3 * TX_SLOT,              // [2 bufs][dz(MID), dz(MID) o s_out]
   TX_O_SGN = TX_O_DZM + 2 * 2 * TX_PM, // [3 slots][80 words]
   TX_O_LUT = TX_O_SGN + 3 * 80 * 4,    // 256 x 16 B sign-byte -> XOR mask
-  // mask sources, LDS-DMA'd two steps ahead into a ring of 4: bit masks [MID > 0] [32 rows][16 B] | [ACT1 > 0] [32][16 B] |
+  // mask sources, LDS-DMA'd five / six steps ahead into a ring of 8: bit masks [MID > 0] [32 rows][16 B] | [ACT1 > 0] [32][16 B] |
   // 2-bit arg-max codes [32][32 B] (planes written by the forward).  Not part of the zero fill: the DMA may land first.
   TX_PD = 512, TX_PC = 1024,
   TX_DSLOT = 2 * TX_PD + TX_PC,
   TX_O_DMA = TX_O_LUT + 4096,
-  TX_O_MLUT = TX_O_DMA + 4 * TX_DSLOT,   // 16 x 8 B: mask nibble -> AND masks of 4 bf16 values
+  TX_O_MLUT = TX_O_DMA + 8 * TX_DSLOT,   // 16 x 8 B: mask nibble -> AND masks of 4 bf16 values
   TX_LDS = TX_O_MLUT + 128
 };
 
@@ -100,28 +100,30 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
       }
     };
     auto issue_mid = [&](int k) __attribute__((always_inline)) {
-      if (k < nwin) dma_rows(A.m_mid, Rs + k * Rstep, 16, lds0 + (uint32_t)((k & 3) * TX_DSLOT));
+      if (k < nwin) dma_rows(A.m_mid, Rs + k * Rstep, 16, lds0 + (uint32_t)((k & 7) * TX_DSLOT));
     };
     auto issue_a1 = [&](int k) __attribute__((always_inline)) {
       if (k < nwin) {
-        dma_rows(A.m_act1, Rs + k * Rstep, 16, lds0 + (uint32_t)((k & 3) * TX_DSLOT + TX_PD));
-        dma_rows(A.amax, Rs + k * Rstep, 32, lds0 + (uint32_t)((k & 3) * TX_DSLOT + 2 * TX_PD));
+        dma_rows(A.m_act1, Rs + k * Rstep, 16, lds0 + (uint32_t)((k & 7) * TX_DSLOT + TX_PD));
+        dma_rows(A.amax, Rs + k * Rstep, 32, lds0 + (uint32_t)((k & 7) * TX_DSLOT + 2 * TX_PD));
       }
     };
-    constexpr int n_m = 1, n_c = 1;
-    const int per_mid = n_m, per_a1 = n_m + n_c;
-    // in-flight bookkeeping: number of DMA instructions issued in the current and the previous step
-    issue_mid(0); issue_a1(0); issue_mid(1); issue_a1(1); issue_mid(2);
-    int prev = (2 < nwin ? per_mid : 0);   // what may still fly after the prologue wait: MID hi of window 2
-    if constexpr (!(TX_ABL & 4)) BNN_WAIT_VMCNT_WIDE(prev);             // windows 0 / 1 landed
+    constexpr int per_mid = 1, per_a1 = 2;
+    // step t issues the MID masks of window t+6 and the ACT1 masks / codes of window t+5 and waits until only the DMAs of
+    // the last four steps are in flight: what the stages read at step t+1 (MID of t+1, ACT1 / codes of t) was issued at
+    // least five steps (>= 10 us) ago - HBM latency under load is 2-3 us
+    for (int k = 0; k < 6; ++k) issue_mid(k);
+    for (int k = 0; k < 5; ++k) issue_a1(k);
+    if constexpr (!(TX_ABL & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int p1 = 0, p2 = 0, p3 = 0;   // instructions issued one / two / three steps ago
     __syncthreads();
     lds_barrier();
     for (int t = 0; t < nsteps; ++t) {
-      issue_mid(t + 3);
-      issue_a1(t + 2);
-      const int cur = (t + 3 < nwin ? per_mid : 0) + (t + 2 < nwin ? per_a1 : 0);
-      if constexpr (!(TX_ABL & 4)) BNN_WAIT_VMCNT_WIDE(cur + prev);
-      prev = cur;
+      issue_mid(t + 6);
+      issue_a1(t + 5);
+      const int cur = (t + 6 < nwin ? per_mid : 0) + (t + 5 < nwin ? per_a1 : 0);
+      if constexpr (!(TX_ABL & 4)) BNN_WAIT_VMCNT_WIDE(cur + p1 + p2 + p3);
+      p3 = p2; p2 = p1; p1 = cur;
       lds_barrier();
     }
     return;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         const uint32_t* sg = (const uint32_t*)(smem + TX_O_SGN) + (k % 3) * 80;
         const unsigned R0 = (unsigned)(Rs + k * Rstep);
         char* dzm = smem + TX_O_DZM + (k & 1) * 2 * TX_PM;
-        const char* dsl = smem + TX_O_DMA + (k & 3) * TX_DSLOT;   // MID hi of this window (LDS-DMA'd)
+        const char* dsl = smem + TX_O_DMA + (k & 7) * TX_DSLOT;   // MID hi of this window (LDS-DMA'd)
 #pragma unroll
         for (int jj = 0; jj < TX_NJ; ++jj) {
           const int j = jb + jj;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
               if (row < L) {
                 const uint32_t mb = *(const unsigned char*)(dsl + row * 16 + (och >> 3));
                 const uint2 mk = *(const uint2*)(smem + TX_O_MLUT + ((mb >> (och & 4)) & 15u) * 8);
-                uint2 d = pack_bf4(acc[mt]);
+                uint2 d = make_uint2(cvt_pk(acc[mt][0], acc[mt][1]), cvt_pk(acc[mt][2], acc[mt][3]));
                 d.x &= mk.x;
                 d.y &= mk.y;
                 const int o = (row + HALO) * TR_RSB + och * 2;
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         const char* sl = smem + TX_O_SLOT + (k % 3) * TX_SLOT;
         const uint32_t* sg = (const uint32_t*)(smem + TX_O_SGN) + (k % 3) * 80;
         const char* dzm = smem + TX_O_DZM + (k & 1) * 2 * TX_PM;
-        const char* dsl = smem + TX_O_DMA + (k & 3) * TX_DSLOT;   // ACT1 hi + codes of this window (LDS-DMA'd)
+        const char* dsl = smem + TX_O_DMA + (k & 7) * TX_DSLOT;   // ACT1 hi + codes of this window (LDS-DMA'd)
         const unsigned R0 = (unsigned)(Rs + k * Rstep);
         f32x4 acc[2], accp[2];
         acc[0] = acc[1] = accp[0] = accp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
           if (row < L) {
             const uint32_t mb = *(const unsigned char*)(dsl + TX_PD + row * 16 + (och >> 3));
             const uint2 mk = *(const uint2*)(smem + TX_O_MLUT + ((mb >> (och & 4)) & 15u) * 8);
-            uint2 d = pack_bf4(v[mt]);
+            uint2 d = make_uint2(cvt_pk(v[mt][0], v[mt][1]), cvt_pk(v[mt][2], v[mt][3]));
             d.x &= mk.x;
             d.y &= mk.y;
             if constexpr (!(TX_ABL & 1)) *(uint2*)((char*)A.g_act1 + ((R0 + (unsigned)row) * 256u + (unsigned)(och * 2))) = d;
