@@ -651,7 +651,7 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
       const long n = ((p->P + 3) / 4) * S;
       // particle offset is folded into the step word for predict chunks.  Flipout: generated by the sign kernel's
       // launch below (one launch less)
-      if (c->mode == BNN_MODE_FLIPOUT) eps_deferred = true;
+      if (false && c->mode == BNN_MODE_FLIPOUT) eps_deferred = true;   // (merging made the sign kernel's grid 2.5x larger: slower)
       else gen_eps_w_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(e, p->P, S, seed + 0x9E37ull * c->s_base, step);
       c->eps_w = e;
     }
