@@ -94,25 +94,9 @@ struct SignGenArgs {
   int words[2 * BNN_MAX_LAYERS];
   int layer[2 * BNN_MAX_LAYERS];
   uint32_t kind[2 * BNN_MAX_LAYERS];
-  // optional extra entry blockIdx.y == n: the weight noise eps_w[S][P] of the same step (one launch less)
-  float* eps;
-  long P;
-  uint64_t eps_seed;
 };
 __global__ void gen_signs_all_kernel(const SignGenArgs A) {
   const int e = blockIdx.y;
-  if (e == A.n) {   // gen_eps_w_kernel's work
-    const long n4 = (A.P + 3) >> 2;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n4 * A.S) return;
-    const int s = (int)(idx / n4);
-    const long q = idx - (long)s * n4;
-    const f32x4 z = philox_normal4((uint32_t)q, (uint32_t)s, NK_EPSW, A.step, A.eps_seed);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (q * 4 + r < A.P) A.eps[(long)s * A.P + q * 4 + r] = z[r];
-    return;
-  }
   const int words = A.words[e];
   const int w4 = (words + 3) >> 2;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

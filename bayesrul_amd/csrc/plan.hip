@@ -642,17 +642,14 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
   c->nz.step = step;
   const int S = c->S, B = c->B;
   const bool need_eps = c->mode != BNN_MODE_LRT;
-  bool eps_deferred = false;
   if (need_eps) {
     if (nz && nz->eps_w) {
       c->eps_w = nz->eps_w;
     } else {
       float* e = ws_f(p, p->o_eps);
       const long n = ((p->P + 3) / 4) * S;
-      // particle offset is folded into the step word for predict chunks.  Flipout: generated by the sign kernel's
-      // launch below (one launch less)
-      if (false && c->mode == BNN_MODE_FLIPOUT) eps_deferred = true;   // (merging made the sign kernel's grid 2.5x larger: slower)
-      else gen_eps_w_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(e, p->P, S, seed + 0x9E37ull * c->s_base, step);
+      // particle offset is folded into the step word for predict chunks
+      gen_eps_w_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(e, p->P, S, seed + 0x9E37ull * c->s_base, step);
       c->eps_w = e;
     }
   }
@@ -698,15 +695,10 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
         SG.n++;
       }
     }
-    long n = SG.n > 0 ? ex * maxw4 : 0;
-    if (eps_deferred) {
-      SG.eps = ws_f(p, p->o_eps);
-      SG.P = p->P;
-      SG.eps_seed = seed + 0x9E37ull * c->s_base;
-      n = std::max(n, ((p->P + 3) / 4) * S);
+    if (SG.n > 0) {
+      const long n = ex * maxw4;
+      gen_signs_all_kernel<<<dim3((unsigned)((n + 255) / 256), SG.n), dim3(256), 0, c->st>>>(SG);
     }
-    if (SG.n > 0 || eps_deferred)
-      gen_signs_all_kernel<<<dim3((unsigned)((n + 255) / 256), SG.n + (eps_deferred ? 1 : 0)), dim3(256), 0, c->st>>>(SG);
   }
   c->nz.use_philox_lrt = 1;
   c->nz.examples = (long)S * B;
