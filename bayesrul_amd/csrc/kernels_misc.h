@@ -210,7 +210,7 @@ __global__ void prep_weights_kernel(const PrepArgs A) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = e < A.T.P;
   const int lane = threadIdx.x & 63;
-  __shared__ double red[8];
+  __shared__ double red[16];   // up to 1024 threads per workgroup
   constexpr int RS_MAX = 128;
   __shared__ double red_s[RS_MAX];   // radial: per-particle partial sums of this workgroup
   const int radial = (A.mode == 3);

@@ -745,12 +745,12 @@ static int do_sample(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
   A.kl_acc = (double*)(w + p->o_acc);
   A.prior_loc = (float)a->prior_loc;
   A.prior_scale = (float)a->prior_scale;
-  const unsigned grid = (unsigned)((p->P + 255) / 256);
+  const unsigned grid = (unsigned)((p->P + 1023) / 1024);   // 1024-thread workgroups: four times fewer fp64 atomics on the KL sum
   ProfScope ps_(&p->prof, PK_SAMPLE, 0, c->st);
   if (p->d.prec == BNN_PREC_F32)
-    prep_weights_kernel<PrecF32><<<dim3(grid), dim3(256), 0, c->st>>>(A);
+    prep_weights_kernel<PrecF32><<<dim3(grid), dim3(1024), 0, c->st>>>(A);
   else
-    prep_weights_kernel<PrecBF><<<dim3(grid), dim3(256), 0, c->st>>>(A);
+    prep_weights_kernel<PrecBF><<<dim3(grid), dim3(1024), 0, c->st>>>(A);
   HIP_TRY(hipGetLastError());
   return 0;
 }
