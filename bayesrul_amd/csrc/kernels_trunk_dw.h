@@ -86,10 +86,12 @@ struct Dw1Job {
         const char* b0 = xi + ra * 64 + ((cb ^ ((ra >> 2) & 3)) << 4) + 8 * (p & 1);
         const char* b1 = xi + rb * 64 + ((cb ^ ((rb >> 2) & 3)) << 4) + 8 * (p & 1);
         const bf16x8 fb = tr_frag2(b0, b1);
-        acc_a[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc_a[t][c], 0, 0, 0);
+        // operands swapped: the tile is accumulated TRANSPOSED (rows = input channels, columns = couts), so a lane ends up
+        // with 4 consecutive input channels of one cout = one 16-byte store in flush()
+        acc_a[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa, acc_a[t][c], 0, 0, 0);
         if constexpr (FO) {
           const bool ni = (sg[LAYER * 2] >> ((CT0 + c) * 16 + (lane & 15))) & 1u;
-          acc_b[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fas, xor_sign(fb, ni), acc_b[t][c], 0, 0, 0);
+          acc_b[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xor_sign(fb, ni), fas, acc_b[t][c], 0, 0, 0);
         }
       }
     }
@@ -104,16 +106,13 @@ struct Dw1Job {
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
       for (int c = 0; c < NCT; ++c) {
-        const int ch = (CT0 + c) * 16 + jc;
-        if (ch >= ly.cin) continue;   // channel pads of the x image
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = NT * 16 + i4 + r;
-          if (n >= ly.cout) continue;
-          const long o = (long)n * ly.KP + (long)t * ly.cin_img + ch;
-          gwa[o] = acc_a[t][c][r];
-          if constexpr (FO) gwb[o] = acc_b[t][c][r];
-        }
+        // transposed tile: this lane holds input channels ch .. ch+3 of cout n (channel pads of the x image are zero
+        // columns: their sums are zeros)
+        const int ch = (CT0 + c) * 16 + i4, n = NT * 16 + jc;
+        if (n >= ly.cout) continue;
+        const long o = (long)n * ly.KP + (long)t * ly.cin_img + ch;
+        *(f32x4*)(gwa + o) = acc_a[t][c];
+        if constexpr (FO) *(f32x4*)(gwb + o) = acc_b[t][c];
       }
     if constexpr (BIAS) {
       if ((lane & 15) == 0) {
@@ -340,11 +339,13 @@ struct Dw2Job {
         const char* b0 = xi + ra * 256 + ((cb ^ fa_) << 4) + 8 * (p & 1);
         const char* b1 = xi + rb * 256 + ((cb ^ fb_) << 4) + 8 * (p & 1);
         const bf16x8 fb = tr_frag2(b0, b1);
-        acc_a[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc_a[t][c], 0, 0, 0);
+        // operands swapped: the tile is accumulated TRANSPOSED (rows = input channels, columns = couts), so a lane ends up
+        // with 4 consecutive input channels of one cout = one 16-byte store in flush()
+        acc_a[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa, acc_a[t][c], 0, 0, 0);
         if constexpr (FO) {
           const int cbit = (CT0 + c) * 16;   // bit of the layer's own input channel
           const bool ni = (sg[cbit >> 5] >> ((cbit & 31) + (lane & 15))) & 1u;
-          acc_b[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fas, xor_sign(fb, ni), acc_b[t][c], 0, 0, 0);
+          acc_b[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xor_sign(fb, ni), fas, acc_b[t][c], 0, 0, 0);
         }
       }
     }
@@ -359,16 +360,13 @@ struct Dw2Job {
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
       for (int c = 0; c < NCT; ++c) {
-        const int ch = (CT0 + c) * 16 + jc;   // image channel of the layer's input
-        if (ly.cmap == CM_BLOCK && (ch % ly.cmap_b) >= ly.cmap_a) continue;   // block pads (27 -> 32) carry no weight
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = NT * 16 + i4 + r;
-          if (n >= ly.cout) continue;
-          const long o = (long)n * ly.KP + (long)t * ly.cin_img + ch;
-          gwa[o] = acc_a[t][c][r];
-          if constexpr (FO) gwb[o] = acc_b[t][c][r];
-        }
+        // transposed tile: this lane holds image channels ch .. ch+3 of cout n (block pads 27 -> 32 of the input are zero
+        // columns: their sums are zeros)
+        const int ch = (CT0 + c) * 16 + i4, n = NT * 16 + jc;
+        if (n >= ly.cout) continue;
+        const long o = (long)n * ly.KP + (long)t * ly.cin_img + ch;
+        *(f32x4*)(gwa + o) = acc_a[t][c];
+        if constexpr (FO) *(f32x4*)(gwb + o) = acc_b[t][c];
       }
     if constexpr (BIAS) {
       if ((lane & 15) == 0) {
