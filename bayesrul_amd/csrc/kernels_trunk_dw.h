@@ -444,107 +444,85 @@ __global__ __launch_bounds__(TW2A_THREADS) void trunk_dw2a_kernel(const TrunkDw2
     for (int k = tid; k < TW2A_LDS / 4; k += TW2A_THREADS) z[k] = 0u;
   }
   if (wave >= TW2A_NC) {
-    // =========================== loaders: pair p stages the windows k = p (mod 2) ===========================
-    // role 0: ACT1 hi plane + its MaxPool1d(3,1,1) copy (built from the image it has just written: one wave, in-order
-    // LDS traffic); role 1: dz(MID), dz(ACT2), sign words
-    const int p = (wave - TW2A_NC) >> 1, lw = (wave - TW2A_NC) & 1;
-    const int nz = L * 16, n2 = L * 10;
+    // =========================== loaders ===========================
+    // EVERY loader wave stages a quarter (8 rows) of EVERY window: the ACT1 hi plane and its MaxPool1d(3,1,1) copy (the
+    // wave loads its rows plus one halo row on each side, so the pooled rows come out of registers), dz(MID), dz(ACT2);
+    // wave 0 also the sign words.  Loads are issued two windows ahead (compile-time ring of 2 register sets).  With one wave per window the staging work of a window (27 LDS stores, the pooled copy) WAS the step.
+    const int w = wave - TW2A_NC;
+    const int c = lane & 15, a0 = 8 * w + 2 * (lane >> 4);   // this lane's rows a0, a0 + 1 of piece c
+    const int zrow = 8 * w + lane / 6, zcc = lane % 6, zc = zcc < 2 ? zcc : zcc + 4;   // dz(ACT2): 6 of the row's 10 pieces
+    const bool z_on = lane < 48 && zrow < L;
     auto wrow = [&](int k) __attribute__((always_inline)) { return ((long)s * A.B + split + (long)k * A.nsplit) * L; };
-    // window k: fetched at step k-3 (or in the prologue), put during step k-1; step k computes window k
-#define TW2_LOADER_LOOP(FETCH, PUT)          \
-  do {                                       \
-    if (p < nwin) FETCH(p);                  \
-    __syncthreads();                         \
-    if (p == 0 && nwin > 0) PUT(0);          \
-    if (p == 0 && 2 < nwin) FETCH(2);        \
-    lds_barrier();                           \
-    for (int t = 0; t < nwin; ++t) {         \
-      const int k = t + 1;                   \
-      if ((k & 1) == p) {                    \
-        if (k < nwin) PUT(k);                \
-        if (k + 2 < nwin) FETCH(k + 2);      \
-      }                                      \
-      lds_barrier();                         \
-    }                                        \
-  } while (0)
-    if (lw == 0) {
-      tr_u32x4 b[8];   // ext_vector registers (arrays of HIP's uint4 struct are not split into registers)
-      auto fetch = [&](int k) __attribute__((always_inline)) {
-        const char* src = (const char*)A.x_hi + wrow(k) * 256;
+    const uint32_t* sgp = nullptr;
+    long sgs = 0;
+    if (w == 0) dw2_sign_setup(A, s, split, lane, sgp, sgs);
+    struct Set {
+      tr_u32x4 x[4], g[2], z;
+      uint32_t sw;
+    };
+    auto load = [&](int k, Set& S) __attribute__((always_inline)) {
+      const long R0 = wrow(k);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int q = j * 64 + lane, qq = q < nz ? q : 0;
-          b[j] = *(const tr_u32x4*)(src + qq * 16);
-        }
-      };
-      auto put = [&](int k) __attribute__((always_inline)) {
-        char* sl = smem + (k % 3) * TW2A_SLOT;
+      for (int j = 0; j < 4; ++j) {
+        const int row = min(max(a0 - 1 + j, 0), L - 1);   // clamped; rows outside the window are zeroed in put()
+        S.x[j] = *(const tr_u32x4*)((const char*)A.x_hi + (R0 + row) * 256 + c * 16);
+      }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int q = j * 64 + lane;
-          const int ri = (q >> 4) + HALO, c = q & 15;
-          if (q < nz) *(tr_u32x4*)(sl + ri * 256 + ((c ^ f128(ri)) << 4)) = b[j];
-        }
-        // pooled copy: max over rows ri-1, ri, ri+1 (halo rows and rows >= L are zero; values are >= 0)
+      for (int j = 0; j < 2; ++j) S.g[j] = *(const tr_u32x4*)((const char*)A.g_mid + (R0 + min(a0 + j, L - 1)) * 256 + c * 16);
+      S.z = *(const tr_u32x4*)((const char*)A.g_act2 + (R0 + (z_on ? zrow : 0)) * 160 + (z_on ? zc : 0) * 16);
+      S.sw = 0u;
+      if constexpr (FO) {
+        if (sgp) S.sw = sgp[(long)k * sgs];
+      }
+    };
+    auto put = [&](int k, const Set& S) __attribute__((always_inline)) {
+      char* sl = smem + (k % 3) * TW2A_SLOT;
+      tr_u32x4 x[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int q = j * 64 + lane;
-          const int ri = (q >> 4) + HALO, c = q & 15;
-          if (q < nz) {
-            const tr_u32x4 u = *(const tr_u32x4*)(sl + (ri - 1) * 256 + ((c ^ f128(ri - 1)) << 4));
-            const tr_u32x4 d = *(const tr_u32x4*)(sl + (ri + 1) * 256 + ((c ^ f128(ri + 1)) << 4));
-            tr_u32x4 m = b[j];
+      for (int j = 0; j < 4; ++j) {
+        const int row = a0 - 1 + j;
+        x[j] = (row >= 0 && row < L) ? S.x[j] : tr_u32x4{0u, 0u, 0u, 0u};   // values are >= 0: zero is the pool's identity
+      }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) m[e] = max2_bf16_pos(max2_bf16_pos(m[e], u[e]), d[e]);
-            *(tr_u32x4*)(sl + TW_PH + ri * 256 + ((c ^ f128(ri)) << 4)) = m;
-          }
-        }
-      };
-      TW2_LOADER_LOOP(fetch, put);
-    } else {
-      tr_u32x4 b[13];
-      uint32_t sw = 0;
-      const uint32_t* sgp;
-      long sgs;
-      dw2_sign_setup(A, s, split, lane, sgp, sgs);
-      auto fetch = [&](int k) __attribute__((always_inline)) {
-        const long R0 = wrow(k);
+      for (int j = 0; j < 2; ++j) {
+        const int row = a0 + j, ri = row + HALO;
+        if (row < L) {
+          *(tr_u32x4*)(sl + ri * 256 + ((c ^ f128(ri)) << 4)) = x[1 + j];
+          tr_u32x4 m;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int q = j * 64 + lane, qq = q < nz ? q : 0;
-          b[j] = *(const tr_u32x4*)((const char*)A.g_mid + R0 * 256 + qq * 16);
+          for (int e = 0; e < 4; ++e) m[e] = max2_bf16_pos(max2_bf16_pos(x[j][e], x[1 + j][e]), x[2 + j][e]);
+          *(tr_u32x4*)(sl + TW_PH + ri * 256 + ((c ^ f128(ri)) << 4)) = m;
+          *(tr_u32x4*)(sl + 2 * TW_PH + row * 256 + ((c ^ f128(row)) << 4)) = S.g[j];
         }
-        // dz(ACT2): only the channels of this kernel's layers (4: pieces 0, 1; 9: pieces 6 .. 9 of the row's 10)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int q = j * 64 + lane, qq = q < L * 6 ? q : 0;
-          const int row = qq / 6, cc = qq - row * 6;
-          b[8 + j] = *(const tr_u32x4*)((const char*)A.g_act2 + (R0 + row) * 160 + (cc < 2 ? cc : cc + 4) * 16);
-        }
-        if constexpr (FO) {
-          if (sgp) sw = sgp[(long)k * sgs];
-        }
-      };
-      auto put = [&](int k) __attribute__((always_inline)) {
-        char* sl = smem + (k % 3) * TW2A_SLOT;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int q = j * 64 + lane;
-          const int row = q >> 4, c = q & 15;
-          if (q < nz) *(tr_u32x4*)(sl + 2 * TW_PH + row * 256 + ((c ^ f128(row)) << 4)) = b[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int q = j * 64 + lane;
-          const int row = q / 6, cc = q - row * 6, c = cc < 2 ? cc : cc + 4;
-          if (q < L * 6) *(tr_u32x4*)(sl + 2 * TW_PH + TW_PZ + row * 256 + ((c ^ f128(row)) << 4)) = b[8 + j];
-        }
-        if constexpr (FO) {
-          if (lane < 48) ((uint32_t*)(smem + TW2A_O_SGN))[(k % 3) * 48 + lane] = sw;
-        }
-      };
-      TW2_LOADER_LOOP(fetch, put);
+      }
+      if (z_on) *(tr_u32x4*)(sl + 2 * TW_PH + TW_PZ + zrow * 256 + ((zc ^ f128(zrow)) << 4)) = S.z;
+      if constexpr (FO) {
+        if (w == 0 && lane < 48) ((uint32_t*)(smem + TW2A_O_SGN))[(k % 3) * 48 + lane] = S.sw;
+      }
+    };
+    Set s0, s1;
+    if (0 < nwin) load(0, s0);
+    if (1 < nwin) load(1, s1);
+    __syncthreads();   // zero fill visible
+    if (nwin > 0) {
+      put(0, s0);
+      if (2 < nwin) load(2, s0);
     }
+    lds_barrier();     // window 0 staged
+    // step t (compute waves: window t): window t+1 from register set (t+1) % 2, which is then reloaded with window t+3
+#define TW2A_STEP(T, SET)                        \
+  do {                                           \
+    if ((T) + 1 < nwin) {                        \
+      put((T) + 1, SET);                         \
+      if ((T) + 3 < nwin) load((T) + 3, SET);    \
+    }                                            \
+    lds_barrier();                               \
+  } while (0)
+    for (int t = 0; t < nwin; t += 2) {
+      TW2A_STEP(t, s1);
+      if (t + 1 < nwin) TW2A_STEP(t + 1, s0);
+    }
+#undef TW2A_STEP
     return;
   }
 #define DW2A_ROLE(LY, NT) dw2_role<EM, TW2A_SLOT, TW2A_O_SGN, Dw2Job<EM, true, LY, NT, 0, 8, true>, Dw2Empty>(A, smem, s, nwin, lane)
