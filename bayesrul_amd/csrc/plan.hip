@@ -595,6 +595,7 @@ struct Ctx {
   int objective = 0;   // 0 ELBO; 1 / 2: frequentist objectives (bnn_det_step)
   NoiseRefs nz{};
   int s_base = 0;  // particle offset for noise streams (predict chunks)
+  bool x_planes_ready = false;   // predictive pass, chunks after the first: the planes of x are already in the workspace
   bool grads_zeroed = false;     // the gradient images need no fill in do_backward (done earlier, or every element is stored)
   bool last_fused = false;       // Inception trunk path: the last layer Linear(64, 2) runs inside the fin / head kernels
   bool head_fused = false;       // bnn_elbo_step on the fused Linear-net path: the head runs inside the backward's first kernel
@@ -1542,7 +1543,7 @@ static int launch_trunk_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, cons
   const long rows = (long)c->B * L;
   const size_t plane = (size_t)p->d.max_batch * L * 32;
   u16* xp = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
-  if (!g_dry) {
+  if (!g_dry && !c->x_planes_ready) {
     x_planes4_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xp, xp + plane, xp + 2 * plane,
                                                                                         xp + 3 * plane, rows, L, p->d.n_features);
     HIP_TRY(hipGetLastError());
@@ -2218,6 +2219,7 @@ extern "C" int bnn_predict(BnnPlan* p, const float* x, int32_t batch, int32_t pa
     Ctx c;
     BNN_TRY(make_ctx(p, &a, &n2, stream, false, &c));
     c.s_base = s0;
+    c.x_planes_ready = s0 > 0;   // same windows for every chunk of particles
       BNN_TRY(prepare_noise(p, &a, &n2, &c));
     BNN_TRY(do_sample(p, &a, &c));
     BNN_TRY(do_forward(p, &a, &c, x));
