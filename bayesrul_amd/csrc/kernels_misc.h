@@ -443,6 +443,36 @@ __global__ void finish_loss_kernel(const LossArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// ClippedAdam on the flat (mu, rho) buffer  (A12)
+// ------------------------------------------------------------------------------------------
+struct AdamArgs {
+  float* mu; float* rho; float* m; float* v; const float* grad;
+  long P;
+  float lr, beta1, beta2, eps, clip, wd, step_size, grad_scale;
+  int freeze_loc, freeze_scale;
+};
+
+// element i of the flat (mu | rho) buffer, raw gradient g0
+__device__ __forceinline__ void adam_update(const AdamArgs& A, long i, float g0) {
+  if (i < A.P ? A.freeze_loc : A.freeze_scale) return;
+  float* p = i < A.P ? A.mu + i : A.rho + (i - A.P);
+  float g = g0 * A.grad_scale;
+  g = fminf(fmaxf(g, -A.clip), A.clip);
+  if (A.wd != 0.f) g += A.wd * *p;
+  const float m = A.beta1 * A.m[i] + (1.f - A.beta1) * g;
+  const float v = A.beta2 * A.v[i] + (1.f - A.beta2) * g * g;
+  A.m[i] = m;
+  A.v[i] = v;
+  *p -= A.step_size * m / (sqrtf(v) + A.eps);
+}
+
+__global__ void clipped_adam_kernel(const AdamArgs A) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * A.P) return;
+  adam_update(A, i, A.grad[i]);
+}
+
+// ------------------------------------------------------------------------------------------
 // chain rule: weight-image gradients -> d loss / d (mu, rho)   (+ KL / prior terms)
 //   G = d(-sum_b ll_b)/dW per particle (unscaled); scale_ll = c*(N/B)/S
 // ------------------------------------------------------------------------------------------
@@ -460,6 +490,8 @@ struct FinalizeArgs {
   float* grad;      // [2P]
   LossArgs loss;    // fused_loss: thread 0 of workgroup 0 also finishes the loss scalars (the accumulators are complete:
   int fused_loss;   // the head ran earlier on the stream)
+  AdamArgs adam;    // fused_adam: the optimizer update of the element follows at once (single-GPU step: no all-reduce
+  int fused_adam;   // between the two)
 };
 
 __global__ void grad_finalize_kernel(const FinalizeArgs A) {
@@ -528,6 +560,10 @@ __global__ void grad_finalize_kernel(const FinalizeArgs A) {
   }
   A.grad[e] = dmu;
   A.grad[A.T.P + e] = drho;
+  if (A.fused_adam) {
+    adam_update(A.adam, e, dmu);
+    adam_update(A.adam, A.T.P + e, drho);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -573,31 +609,6 @@ __global__ void slab_reduce_kernel(const SlabReduceJobs J) {
   }
   for (; k < n; ++k) t[0] += p[(long)k * A.stride];
   A.out[(long)s * A.out_stride + e] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-}
-
-// ------------------------------------------------------------------------------------------
-// ClippedAdam on the flat (mu, rho) buffer  (A12)
-// ------------------------------------------------------------------------------------------
-struct AdamArgs {
-  float* mu; float* rho; float* m; float* v; const float* grad;
-  long P;
-  float lr, beta1, beta2, eps, clip, wd, step_size, grad_scale;
-  int freeze_loc, freeze_scale;
-};
-
-__global__ void clipped_adam_kernel(const AdamArgs A) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * A.P) return;
-  if (i < A.P ? A.freeze_loc : A.freeze_scale) return;
-  float* p = i < A.P ? A.mu + i : A.rho + (i - A.P);
-  float g = A.grad[i] * A.grad_scale;
-  g = fminf(fmaxf(g, -A.clip), A.clip);
-  if (A.wd != 0.f) g += A.wd * *p;
-  const float m = A.beta1 * A.m[i] + (1.f - A.beta1) * g;
-  const float v = A.beta2 * A.v[i] + (1.f - A.beta2) * g * g;
-  A.m[i] = m;
-  A.v[i] = v;
-  *p -= A.step_size * m / (sqrtf(v) + A.eps);
 }
 
 // ------------------------------------------------------------------------------------------

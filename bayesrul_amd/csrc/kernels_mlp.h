@@ -21,11 +21,15 @@
 #define ML_ABL 0
 #endif
 
+// forward and dX chain: windows of MLF_ROWS rows (their cost is VALU issue in the epilogues, so more, smaller workgroups);
+// dW: windows of ML_ROWS rows (one MFMA k-step of the row contraction)
+enum { MLF_MT = 1, MLF_ROWS = 16 * MLF_MT };
 enum { ML_ROWS = 32, ML_K0 = 544, ML_N0 = 256, ML_N1 = 128, ML_N2 = 128, ML_N3 = 32, ML_N4 = 2 };
 // LDS activation image: three planes (hi | lo | squared hi), ML_ROWS rows, pitch = K * 2 + 32 bytes: pitch / 16 = 2 (mod 4)
 // for every K here, conflict-free for the ds_read_b128 lane groups (see TR_RSB in kernels_trunk.h)
 __host__ __device__ constexpr int ml_pitch(int K) { return K * 2 + 32; }
 __host__ __device__ constexpr int ml_plane(int K) { return ML_ROWS * ml_pitch(K); }
+__host__ __device__ constexpr int mlf_plane(int K) { return MLF_ROWS * ml_pitch(K); }
 
 struct MlpPlan {
   LayerDesc ly[5];     // by value: kernel arguments, not global loads (see DenseKsPlan)
@@ -67,16 +71,16 @@ __device__ __forceinline__ void ml_load(MlFrag<KS>& f, const WeightSlots& ws, co
 // mean (three independent accumulation chains, summed by the caller) and variance contractions of one n-tile over the
 // window image at `in` (hi plane; lo and squared planes `plane` and 2 * `plane` bytes further)
 template <int KS>
-__device__ __forceinline__ void ml_mma(const MlFrag<KS>& f, const char* in, int pitch, int plane, int lane, f32x4 (&am)[2], f32x4 (&av)[2]) {
+__device__ __forceinline__ void ml_mma(const MlFrag<KS>& f, const char* in, int pitch, int plane, int lane, f32x4 (&am)[MLF_MT], f32x4 (&av)[MLF_MT]) {
   const int i16 = lane & 15, g4 = lane >> 4;
   const char* lb = in + i16 * pitch + g4 * 16;
-  f32x4 a1[2], a2[2];
+  f32x4 a1[MLF_MT], a2[MLF_MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) am[mt] = av[mt] = a1[mt] = a2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MLF_MT; ++mt) am[mt] = av[mt] = a1[mt] = a2[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < ((ML_ABL & 2) ? 0 : KS); ++ks)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MLF_MT; ++mt) {
       const char* p = lb + mt * 16 * pitch + ks * 64;
       const bf16x8 bh = *(const bf16x8*)p;
       const bf16x8 bl = *(const bf16x8*)(p + plane);
@@ -87,7 +91,7 @@ __device__ __forceinline__ void ml_mma(const MlFrag<KS>& f, const char* in, int 
       a2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.lo[ks], bh, a2[mt], 0, 0, 0);
     }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MLF_MT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) am[mt][r] += a1[mt][r] + a2[mt][r];
 }
@@ -109,15 +113,15 @@ __device__ __forceinline__ uint2 ml_sq4(uint2 h) {
 
 // LRT epilogue of one n-tile: noise, ReLU, the next layer's LDS planes (TO_LDS) and the global planes / q
 template <bool TO_LDS>
-__device__ __forceinline__ void ml_epilogue(const GroupArgs& A, const LayerDesc& ly, int layer, int nt, const f32x4 (&am)[2],
-                                            const f32x4 (&av)[2], f32x4 ba, f32x4 bb, int out_row0, int nvalid,
+__device__ __forceinline__ void ml_epilogue(const GroupArgs& A, const LayerDesc& ly, int layer, int nt, const f32x4 (&am)[MLF_MT],
+                                            const f32x4 (&av)[MLF_MT], f32x4 ba, f32x4 bb, int out_row0, int nvalid,
                                             const TensorRef& tout, const TensorRef& tq, bool relu, char* out_hi, int opitch,
                                             int oplane, int lane) {
   const int i16 = lane & 15, g4 = lane >> 4;
   const int chb = nt * 16 + 4 * g4;
   const int nv = ly.cout - chb;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MLF_MT; ++mt) {
     const int row = mt * 16 + i16;
     const int R = out_row0 + min(row, nvalid - 1);
     f32x4 eps = {0.f, 0.f, 0.f, 0.f};
@@ -167,20 +171,74 @@ __device__ __forceinline__ void ml_epilogue(const GroupArgs& A, const LayerDesc&
   }
 }
 
+// The same for a hidden layer (cout a multiple of 16, bf16 planes): no per-channel tails, packed stores
+template <bool TO_LDS>
+__device__ __forceinline__ void ml_epilogue_h(const GroupArgs& A, const LayerDesc& ly, int layer, int nt, const f32x4 (&am)[MLF_MT],
+                                              const f32x4 (&av)[MLF_MT], f32x4 ba, f32x4 bb, int out_row0, int nvalid,
+                                              const TensorRef& tout, const TensorRef& tq, char* out_hi, int opitch, int oplane,
+                                              int lane) {
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int chb = nt * 16 + 4 * g4;
+#pragma unroll
+  for (int mt = 0; mt < MLF_MT; ++mt) {
+    const int row = mt * 16 + i16;
+    const int R = out_row0 + min(row, nvalid - 1);
+    f32x4 eps;
+    if constexpr (ML_ABL & 1) {
+      eps = f32x4{0.5f, -0.5f, 0.25f, 1.f};
+    } else if (A.nz.use_philox_lrt) {
+      const long Rg = global_row(A.cg, 1, R);
+      const uint64_t idx = (uint64_t)Rg * (uint64_t)(ly.cout_p16 >> 2) + (uint64_t)(chb >> 2);
+      eps = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)layer << 8), A.nz.step, A.nz.seed);
+    } else {
+      const float* e = A.nz.lrt_eps[layer] + (long)R * ly.cout + chb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) eps[r] = e[r];
+    }
+    f32x4 v, qv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float loc = am[mt][r] + ba[r];
+      float var = av[mt][r] + bb[r];
+      if (var < 0.f) var = 1e-6f;
+      const float sd = sqrtf(var);
+      v[r] = fmaxf(loc + sd * eps[r], 0.f);
+      qv[r] = sd > 0.f ? eps[r] / (2.f * sd) : 0.f;
+    }
+    uint2 hv, lv;
+    split4(v, hv, lv);
+    if constexpr (TO_LDS) {
+      char* o = out_hi + row * opitch + chb * 2;
+      *(uint2*)o = hv;
+      *(uint2*)(o + oplane) = lv;
+      *(uint2*)(o + 2 * oplane) = ml_sq4(hv);
+    }
+    if (row < nvalid && !(ML_ABL & 4)) {
+      const long o = (long)R * tout.ctot + chb;
+      *(uint2*)((u16*)tout.p + o) = hv;
+      // the next layer reads the LDS planes and the backward only the hi plane: no lo plane in HBM when TO_LDS
+      if constexpr (!TO_LDS) *(uint2*)((u16*)tout.lo + o) = lv;
+      *(uint2*)((u16*)tq.p + (long)R * tq.ctot + chb) = make_uint2(cvt_pk(qv[0], qv[1]), cvt_pk(qv[2], qv[3]));
+    }
+  }
+}
+
 // window index -> (particle, first row inside the particle, first row in the [S*B] row space, valid rows)
 struct MlWin {
   int s, r0, R0, nvalid;
 };
+template <int ROWS>
 __device__ __forceinline__ MlWin ml_win(const CallGeom& cg, int win) {
+  const int pp = (cg.B + ROWS - 1) / ROWS;
   MlWin w;
-  w.s = win / cg.per_particle;
-  w.r0 = (win - w.s * cg.per_particle) * ML_ROWS;
+  w.s = win / pp;
+  w.r0 = (win - w.s * pp) * ROWS;
   w.R0 = w.s * cg.B + w.r0;
-  w.nvalid = min(ML_ROWS, cg.B - w.r0);
+  w.nvalid = min(ROWS, cg.B - w.r0);
   return w;
 }
 
-enum { ML0_LDS = 3 * ML_ROWS * (ML_K0 * 2 + 32) };
+enum { ML0_LDS = 3 * MLF_ROWS * (ML_K0 * 2 + 32) };
 
 // ==========================================================================================
 // layer 0: workgroup = (window, 64-cout group); 4 waves = the group's 4 n-tiles, 17 k-steps each
@@ -190,17 +248,18 @@ __global__ __launch_bounds__(256) void mlp_l0_kernel(const GroupArgs A, const Ml
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ng = blockIdx.x & 3;
-  const MlWin W = ml_win(A.cg, blockIdx.x >> 2);
+  const MlWin W = ml_win<MLF_ROWS>(A.cg, blockIdx.x >> 2);
   const LayerDesc& ly = M.ly[0];
-  constexpr int KS = ML_K0 / 32, PITCH = ml_pitch(ML_K0), PLANE = ml_plane(ML_K0);
+  constexpr int KS = ML_K0 / 32, PITCH = ml_pitch(ML_K0), PLANE = mlf_plane(ML_K0);
   constexpr int NU = ML_K0 / 4;   // 4-channel units per row (the last one is channel padding)
   // ---- x window: fp32 rows (broadcast over particles) -> hi / lo / squared planes ----
   const float* x = (const float*)A.t[T_X].p;
   const int xc = A.t[T_X].ctot;   // 540
-  f32x4 xv[17];
+  constexpr int NIT = (MLF_ROWS * NU + 255) / 256;
+  f32x4 xv[NIT];
 #pragma unroll
-  for (int it = 0; it < 17; ++it) {
-    const int u = it * 256 + tid;
+  for (int it = 0; it < NIT; ++it) {
+    const int u = min(it * 256 + tid, MLF_ROWS * NU - 1);
     const int row = u / NU, c4 = u - row * NU;
     const int srow = min(row, W.nvalid - 1), sc = min(c4 * 4, xc - 4);
     xv[it] = *(const f32x4*)(x + (long)(W.r0 + srow) * xc + sc);
@@ -211,8 +270,8 @@ __global__ __launch_bounds__(256) void mlp_l0_kernel(const GroupArgs A, const Ml
   const int chb = nt * 16 + 4 * (lane >> 4);
   const f32x4 ba = ml_bias4(A.ws.bias_a, ly, chb), bb = ml_bias4(A.ws.bias_b, ly, chb);
 #pragma unroll
-  for (int it = 0; it < 17; ++it) {
-    const int u = it * 256 + tid;
+  for (int it = 0; it < NIT; ++it) {
+    const int u = min(it * 256 + tid, MLF_ROWS * NU - 1);   // (the clamped tail rewrites the last unit with the same values)
     const int row = u / NU, c4 = u - row * NU;
     f32x4 v = xv[it];
     if (row >= W.nvalid || c4 * 4 >= xc) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -224,14 +283,14 @@ __global__ __launch_bounds__(256) void mlp_l0_kernel(const GroupArgs A, const Ml
     *(uint2*)(o + 2 * PLANE) = ml_sq4(hv);
     if (ng == 0 && row < W.nvalid && W.s == 0) *(uint2*)(M.xhi + (long)(W.r0 + row) * ML_K0 + c4 * 4) = hv;
   }
-  __syncthreads();
-  f32x4 am[2], av[2];
+  lds_barrier();
+  f32x4 am[MLF_MT], av[MLF_MT];
   ml_mma<KS>(f, smem, PITCH, PLANE, lane, am, av);
-  ml_epilogue<false>(A, ly, 0, nt, am, av, ba, bb, W.R0, W.nvalid, M.h[0], M.q[0], true, nullptr, 0, 0, lane);
+  ml_epilogue_h<false>(A, ly, 0, nt, am, av, ba, bb, W.R0, W.nvalid, M.h[0], M.q[0], nullptr, 0, 0, lane);
 }
 
-enum { ML14_O_H1 = 0, ML14_O_H2 = ML14_O_H1 + 3 * ML_ROWS * (ML_N0 * 2 + 32), ML14_O_H3 = ML14_O_H2 + 3 * ML_ROWS * (ML_N1 * 2 + 32),
-       ML14_O_H4 = ML14_O_H3 + 3 * ML_ROWS * (ML_N2 * 2 + 32), ML14_LDS = ML14_O_H4 + 3 * ML_ROWS * (ML_N3 * 2 + 32) };
+enum { ML14_O_H1 = 0, ML14_O_H2 = ML14_O_H1 + 3 * MLF_ROWS * (ML_N0 * 2 + 32), ML14_O_H3 = ML14_O_H2 + 3 * MLF_ROWS * (ML_N1 * 2 + 32),
+       ML14_O_H4 = ML14_O_H3 + 3 * MLF_ROWS * (ML_N2 * 2 + 32), ML14_LDS = ML14_O_H4 + 3 * MLF_ROWS * (ML_N3 * 2 + 32) };
 
 // ==========================================================================================
 // layers 1..4: workgroup = window; 8 waves; layer 1, 2: one n-tile per wave; layer 3: waves 0, 1; layer 4: wave 0
@@ -240,11 +299,13 @@ __global__ __launch_bounds__(512) void mlp_l14_kernel(const GroupArgs A, const M
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const MlWin W = ml_win(A.cg, blockIdx.x);
+  const MlWin W = ml_win<MLF_ROWS>(A.cg, blockIdx.x);
   // ---- h1 window: bf16 hi / lo planes -> LDS (+ squares): 32 rows x 32 pieces of 16 B per plane ----
-  tr_u32x4 ph[2], pl[2];
+  constexpr int NJ = MLF_ROWS * 32 / 512;
+  static_assert(NJ * 512 == MLF_ROWS * 32, "h1 staging");
+  tr_u32x4 ph[NJ], pl[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int u = j * 512 + tid;
     const int row = u >> 5, c = u & 31;
     const long o = (long)(W.R0 + min(row, W.nvalid - 1)) * M.h[0].ctot + c * 8;
@@ -264,10 +325,10 @@ __global__ __launch_bounds__(512) void mlp_l14_kernel(const GroupArgs A, const M
   const f32x4 ba2 = ml_bias4(A.ws.bias_a, M.ly[2], wave * 16 + 4 * g4), bb2 = ml_bias4(A.ws.bias_b, M.ly[2], wave * 16 + 4 * g4);
   const f32x4 ba3 = ml_bias4(A.ws.bias_a, M.ly[3], (wave & 1) * 16 + 4 * g4), bb3 = ml_bias4(A.ws.bias_b, M.ly[3], (wave & 1) * 16 + 4 * g4);
   const f32x4 ba4 = ml_bias4(A.ws.bias_a, M.ly[4], 4 * g4), bb4 = ml_bias4(A.ws.bias_b, M.ly[4], 4 * g4);
-  constexpr int P1 = ml_pitch(ML_N0), L1 = ml_plane(ML_N0), P2 = ml_pitch(ML_N1), L2 = ml_plane(ML_N1);
-  constexpr int P3 = ml_pitch(ML_N2), L3 = ml_plane(ML_N2), P4 = ml_pitch(ML_N3), L4 = ml_plane(ML_N3);
+  constexpr int P1 = ml_pitch(ML_N0), L1 = mlf_plane(ML_N0), P2 = ml_pitch(ML_N1), L2 = mlf_plane(ML_N1);
+  constexpr int P3 = ml_pitch(ML_N2), L3 = mlf_plane(ML_N2), P4 = ml_pitch(ML_N3), L4 = mlf_plane(ML_N3);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int u = j * 512 + tid;
     const int row = u >> 5, c = u & 31;
     tr_u32x4 h = ph[j], l = pl[j], q;
@@ -279,23 +340,23 @@ __global__ __launch_bounds__(512) void mlp_l14_kernel(const GroupArgs A, const M
     *(tr_u32x4*)(o + L1) = l;
     *(tr_u32x4*)(o + 2 * L1) = q;
   }
-  __syncthreads();
+  lds_barrier();
   // the fragments of layers 3 / 4 are issued here (register pressure: the staging registers are dead now); they land
   // under layers 1 and 2
   ml_load(f3, A.ws, M.ly[3], wave & 1, lane);
   ml_load(f4, A.ws, M.ly[4], 0, lane);
-  f32x4 am[2], av[2];
+  f32x4 am[MLF_MT], av[MLF_MT];
   ml_mma(f1, smem + ML14_O_H1, P1, L1, lane, am, av);
-  ml_epilogue<true>(A, M.ly[1], 1, wave, am, av, ba1, bb1, W.R0, W.nvalid, M.h[1], M.q[1], true, smem + ML14_O_H2, P2, L2, lane);
-  __syncthreads();
+  ml_epilogue_h<true>(A, M.ly[1], 1, wave, am, av, ba1, bb1, W.R0, W.nvalid, M.h[1], M.q[1], smem + ML14_O_H2, P2, L2, lane);
+  lds_barrier();
   ml_mma(f2, smem + ML14_O_H2, P2, L2, lane, am, av);
-  ml_epilogue<true>(A, M.ly[2], 2, wave, am, av, ba2, bb2, W.R0, W.nvalid, M.h[2], M.q[2], true, smem + ML14_O_H3, P3, L3, lane);
-  __syncthreads();
+  ml_epilogue_h<true>(A, M.ly[2], 2, wave, am, av, ba2, bb2, W.R0, W.nvalid, M.h[2], M.q[2], smem + ML14_O_H3, P3, L3, lane);
+  lds_barrier();
   if (wave < 2) {
     ml_mma(f3, smem + ML14_O_H3, P3, L3, lane, am, av);
-    ml_epilogue<true>(A, M.ly[3], 3, wave, am, av, ba3, bb3, W.R0, W.nvalid, M.h[3], M.q[3], true, smem + ML14_O_H4, P4, L4, lane);
+    ml_epilogue_h<true>(A, M.ly[3], 3, wave, am, av, ba3, bb3, W.R0, W.nvalid, M.h[3], M.q[3], smem + ML14_O_H4, P4, L4, lane);
   }
-  __syncthreads();
+  lds_barrier();
   if (wave == 0) {
     ml_mma(f4, smem + ML14_O_H4, P4, L4, lane, am, av);
     ml_epilogue<false>(A, M.ly[4], 4, 0, am, av, ba4, bb4, W.R0, W.nvalid, M.h[4], M.q[4], false, nullptr, 0, 0, lane);
@@ -306,21 +367,21 @@ __global__ __launch_bounds__(512) void mlp_l14_kernel(const GroupArgs A, const M
 // dX chain.  Layer l's contraction: dH_{l-1} = dz_l W_l + 2 H_{l-1} o ((dz_l q_l) sigma_l^2), then
 // dz_{l-1} = dH_{l-1} [H_{l-1} > 0].  Transposed images: [cin][KPt].
 // ==========================================================================================
-enum { MX_PZ = ML_ROWS * (ML_N1 * 2 + 32),   // a dz image of up to 128 channels (pitch 288)
+enum { MX_PZ = MLF_ROWS * (ML_N1 * 2 + 32),   // a dz image of up to 128 channels (pitch 288)
        MX_LDS = 4 * MX_PZ };                 // two buffers x (dz | dz q)
 
 // one 16-channel tile of dH: KS k-steps over the dz images at `zi` (dz) and `zi + MX_PZ` (dz q), pitch `pitch`
 template <int KS>
 __device__ __forceinline__ void mx_tile(const bf16x8 (&wa)[KS], const bf16x8 (&wb)[KS], const char* zi, int pitch, int lane,
-                                        f32x4 (&acc_a)[2], f32x4 (&acc_b)[2]) {
+                                        f32x4 (&acc_a)[MLF_MT], f32x4 (&acc_b)[MLF_MT]) {
   const int i16 = lane & 15, g4 = lane >> 4;
   const char* lb = zi + i16 * pitch + g4 * 16;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) acc_a[mt] = acc_b[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MLF_MT; ++mt) acc_a[mt] = acc_b[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MLF_MT; ++mt) {
       const char* p = lb + mt * 16 * pitch + ks * 64;
       acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks], *(const bf16x8*)p, acc_a[mt], 0, 0, 0);
       acc_b[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks], *(const bf16x8*)(p + MX_PZ), acc_b[mt], 0, 0, 0);
@@ -341,12 +402,12 @@ __device__ __forceinline__ void mx_load(bf16x8 (&wa)[KS], bf16x8 (&wb)[KS], cons
 
 // this lane's 4 channels of H (hi plane) and q of a dH tile, both m-tiles: [mt] -> (H, q) as bf16 pairs
 struct MxEp {
-  uint2 h[2], q[2];
+  uint2 h[MLF_MT], q[MLF_MT];
 };
 __device__ __forceinline__ void mx_ep_load(MxEp& e, const TensorRef& th, const TensorRef& tq, int R0, int nvalid, int t, int lane) {
   const int i16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MLF_MT; ++mt) {
     const long o = (long)(R0 + min(mt * 16 + i16, nvalid - 1)) * th.ctot + t * 16 + 4 * g4;
     e.h[mt] = *(const uint2*)((const u16*)th.p + o);
     e.q[mt] = *(const uint2*)((const u16*)tq.p + o);
@@ -355,11 +416,11 @@ __device__ __forceinline__ void mx_ep_load(MxEp& e, const TensorRef& th, const T
 
 // dH tile -> masked dz and dz q: into the next contraction's LDS images and the global planes for dW
 template <bool TO_LDS>
-__device__ __forceinline__ void mx_finish(const f32x4 (&acc_a)[2], const f32x4 (&acc_b)[2], const MxEp& e, int t, int R0, int nvalid,
+__device__ __forceinline__ void mx_finish(const f32x4 (&acc_a)[MLF_MT], const f32x4 (&acc_b)[MLF_MT], const MxEp& e, int t, int R0, int nvalid,
                                           const TensorRef& tg, const TensorRef& tq, char* zo, int opitch, int lane) {
   const int i16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MLF_MT; ++mt) {
     const int row = mt * 16 + i16;
     const f32x4 xv = unpack_bf4(e.h[mt]), qv = unpack_bf4(e.q[mt]);
     f32x4 g, g2;
@@ -388,7 +449,7 @@ __global__ __launch_bounds__(512) void mlp_dx_kernel(const GroupArgs A, const Ml
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const MlWin W = ml_win(A.cg, blockIdx.x);
+  const MlWin W = ml_win<MLF_ROWS>(A.cg, blockIdx.x);
   // the gradient images of this call start from zero (no separate fill launch)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -399,7 +460,7 @@ __global__ __launch_bounds__(512) void mlp_dx_kernel(const GroupArgs A, const Ml
   // here (predictions, log-likelihood sum, dz), otherwise its output is read.
   float z0 = 0.f, z1 = 0.f, q0 = 0.f, q1 = 0.f;
   {
-    const long R = W.R0 + min(tid & 31, W.nvalid - 1);
+    const long R = W.R0 + min(tid & (MLF_ROWS - 1), W.nvalid - 1);
     q0 = ((const float*)M.q[4].p)[R * 2];
     q1 = ((const float*)M.q[4].p)[R * 2 + 1];
     if (M.fuse_head) {
@@ -431,7 +492,7 @@ __global__ __launch_bounds__(512) void mlp_dx_kernel(const GroupArgs A, const Ml
   char* zb = smem + 2 * MX_PZ;     // buffer B
   constexpr int P32 = ml_pitch(32), P128 = ml_pitch(128);
   // ---- stage dz_4 (K = 2 couts, padded to one 32-channel k-step) ----
-  if (tid < 32) {
+  if (tid < MLF_ROWS) {
     const bool on = tid < W.nvalid;
     const float a0 = on ? z0 : 0.f, a1 = on ? z1 : 0.f;
     const tr_u32x4 d = {cvt_pk(a0, a1), 0u, 0u, 0u}, d2 = {cvt_pk(a0 * q0, a1 * q1), 0u, 0u, 0u}, zz = {0u, 0u, 0u, 0u};
@@ -448,22 +509,22 @@ __global__ __launch_bounds__(512) void mlp_dx_kernel(const GroupArgs A, const Ml
       *(tr_u32x4*)(M.dz4 + M.dz4_plane + (long)(W.R0 + tid) * 8) = d2;
     }
   }
-  __syncthreads();
-  f32x4 acc_a[2], acc_b[2];
+  lds_barrier();
+  f32x4 acc_a[MLF_MT], acc_b[MLF_MT];
   // ---- layer 4: dH_3 (32 channels): waves 0, 1 ----
   if (wave < 2) {
     mx_tile<1>(wa4, wb4, za, P32, lane, acc_a, acc_b);
     mx_finish<true>(acc_a, acc_b, e3, wave, W.R0, W.nvalid, M.g[3], M.q[3], zb, P32, lane);
   }
-  __syncthreads();
+  lds_barrier();
   // ---- layer 3: dH_2 (128 channels), K = 32 ----
   mx_tile<1>(wa3, wb3, zb, P32, lane, acc_a, acc_b);
   mx_finish<true>(acc_a, acc_b, e2, wave, W.R0, W.nvalid, M.g[2], M.q[2], za, P128, lane);
-  __syncthreads();
+  lds_barrier();
   // ---- layer 2: dH_1 (128 channels), K = 128 ----
   mx_tile<4>(wa2, wb2, za, P128, lane, acc_a, acc_b);
   mx_finish<true>(acc_a, acc_b, e1, wave, W.R0, W.nvalid, M.g[1], M.q[1], zb, P128, lane);
-  __syncthreads();
+  lds_barrier();
   // ---- layer 1: dH_0 (256 channels), K = 128: two tiles per wave; only the global planes (layer 0 has no dX) ----
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -512,7 +573,7 @@ __global__ __launch_bounds__(MW_WAVES * 64) void mlp_dw_kernel(const CallGeom cg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ji = blockIdx.x / D.nsplit, split = blockIdx.x - ji * D.nsplit;
   const MlpDwJob& J = D.job[ji];
-  const int B = cg.B, pp = cg.per_particle;
+  const int B = cg.B, pp = (cg.B + ML_ROWS - 1) / ML_ROWS;
   const int nwin = cg.S * pp;   // windows of the whole call: the gradient is summed over particles
   const int nwl = split < nwin ? (nwin - split + D.nsplit - 1) / D.nsplit : 0;
   const int cw = J.cw;
@@ -531,7 +592,7 @@ __global__ __launch_bounds__(MW_WAVES * 64) void mlp_dw_kernel(const CallGeom cg
     }
     const uint32_t lds0 = lds_addr(smem);
     auto issue = [&](int k, int slot) {
-      const MlWin W = ml_win(cg, split + k * D.nsplit);
+      const MlWin W = ml_win<ML_ROWS>(cg, split + k * D.nsplit);
       const int row0 = J.x_bcast ? W.r0 : W.R0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -565,7 +626,7 @@ __global__ __launch_bounds__(MW_WAVES * 64) void mlp_dw_kernel(const CallGeom cg
     const int cc8 = c_on ? c8 : 0;
     const int zo = zrow * 256 + ((c8 ^ f128(zrow)) << 4);
     auto load = [&](int k, tr_u32x4& dz, tr_u32x4& dz2, int& nvw) {
-      const MlWin W = ml_win(cg, split + k * D.nsplit);
+      const MlWin W = ml_win<ML_ROWS>(cg, split + k * D.nsplit);
       nvw = W.nvalid;
       const long o = (long)(W.R0 + min(zrow, nvw - 1)) * J.z_ctot + cc8 * 8;
       dz = *(const tr_u32x4*)(J.dz + o);

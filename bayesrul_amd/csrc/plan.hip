@@ -1434,12 +1434,13 @@ static int launch_mlp_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const 
   fill_mlp_plan(p, &M);
   static_assert(ML0_LDS <= 160 * 1024 && ML14_LDS <= 160 * 1024 && MX_LDS <= 160 * 1024 && MW_LDS <= 160 * 1024, "LDS budgets");
   if (A.t[T_X].ctot != 540 || (A.t[T_X].ctot & 3)) return fail(BNN_E_INVALID, "fused Linear net: %d input features", A.t[T_X].ctot);
+  const int nwf = c->S * ((c->B + MLF_ROWS - 1) / MLF_ROWS);   // forward windows (the dW kernel walks ML_ROWS-row windows)
   {
     ProfScope ps_(&p->prof, PK_FWD, 0, c->st);
     ps_.name("mlp_l0_kernel");
     if (!g_dry) {
       BNN_TRY(set_lds(mlp_l0_kernel, ML0_LDS));
-      mlp_l0_kernel<<<dim3((unsigned)A.cg.nwin * 4), dim3(256), ML0_LDS, c->st>>>(A, M);
+      mlp_l0_kernel<<<dim3((unsigned)nwf * 4), dim3(256), ML0_LDS, c->st>>>(A, M);
     }
   }
   {
@@ -1447,7 +1448,7 @@ static int launch_mlp_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const 
     ps_.name("mlp_l14_kernel");
     if (!g_dry) {
       BNN_TRY(set_lds(mlp_l14_kernel, ML14_LDS));
-      mlp_l14_kernel<<<dim3((unsigned)A.cg.nwin), dim3(512), ML14_LDS, c->st>>>(A, M);
+      mlp_l14_kernel<<<dim3((unsigned)nwf), dim3(512), ML14_LDS, c->st>>>(A, M);
     }
   }
   if (!g_dry) HIP_TRY(hipGetLastError());
@@ -1487,7 +1488,7 @@ static int launch_mlp_bwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     ps_.name("mlp_dx_kernel");
     if (!g_dry) {
       BNN_TRY(set_lds(mlp_dx_kernel, MX_LDS));
-      mlp_dx_kernel<<<dim3((unsigned)A.cg.nwin), dim3(512), MX_LDS, c->st>>>(A, M);
+      mlp_dx_kernel<<<dim3((unsigned)(c->S * ((c->B + MLF_ROWS - 1) / MLF_ROWS))), dim3(512), MX_LDS, c->st>>>(A, M);
     }
   }
   static thread_local MlpDwPlan D;
@@ -1943,8 +1944,15 @@ static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c) {
 
 static void fill_loss_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElboOut* out, bool to_grad, LossArgs* L);
 
-static int do_finalize(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElboOut* fused_out = nullptr, bool fuse_loss = false) {
+static int fill_adam_args(BnnPlan* p, const BnnAdamArgs* ad, AdamArgs* out);
+
+static int do_finalize(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const BnnElboOut* fused_out = nullptr, bool fuse_loss = false,
+                       const BnnAdamArgs* fused_adam = nullptr) {
   FinalizeArgs F{};
+  if (fused_adam) {
+    BNN_TRY(fill_adam_args(p, fused_adam, &F.adam));
+    F.fused_adam = 1;
+  }
   F.T = p->ptab;
   F.layers = (const LayerDesc*)((char*)p->bufs.workspace + p->o_layers);
   F.mu = p->bufs.mu;
@@ -2004,9 +2012,10 @@ static void fill_loss_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const
   LA.grad_tail = to_grad ? p->bufs.grad + 2 * p->P : nullptr;
 }
 
-static int do_adam(BnnPlan* p, const BnnAdamArgs* ad, hipStream_t st) {
+static int fill_adam_args(BnnPlan* p, const BnnAdamArgs* ad, AdamArgs* out) {
   if (!p->bufs.adam_m || !p->bufs.adam_v) return fail(BNN_E_INVALID, "adam_m / adam_v not bound");
-  AdamArgs A{};
+  AdamArgs& A = *out;
+  A = AdamArgs{};
   A.mu = p->bufs.mu;
   A.rho = p->bufs.rho;
   A.m = p->bufs.adam_m;
@@ -2027,6 +2036,12 @@ static int do_adam(BnnPlan* p, const BnnAdamArgs* ad, hipStream_t st) {
   A.freeze_scale = ad->freeze_scale;
   // torch.optim.Adam: p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)  ==  step_size * m / (sqrt(v) + eps * sqrt(bc2))
   if (ad->torch_eps) A.eps = (float)(ad->eps * std::sqrt(bc2));
+  return 0;
+}
+
+static int do_adam(BnnPlan* p, const BnnAdamArgs* ad, hipStream_t st) {
+  AdamArgs A{};
+  BNN_TRY(fill_adam_args(p, ad, &A));
   ProfScope ps_(&p->prof, PK_ADAM, 0, st);
   clipped_adam_kernel<<<dim3((unsigned)((2 * p->P + 255) / 256)), dim3(256), 0, st>>>(A);
   HIP_TRY(hipGetLastError());
@@ -2120,8 +2135,7 @@ extern "C" int bnn_elbo_step(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* n
   BNN_TRY(prepare_fused_tail(p, a, &c));
   if (!c.head_fused) BNN_TRY(do_head(p, a, &c, c.head_preds, true));
   BNN_TRY(do_backward(p, a, &c));
-  BNN_TRY(do_finalize(p, a, &c, out, true));   // + the loss scalars (one launch less)
-  if (adam) BNN_TRY(do_adam(p, adam, c.st));
+  BNN_TRY(do_finalize(p, a, &c, out, true, adam));   // + the loss scalars and the optimizer update (two launches less)
   return 0;
 }
 
