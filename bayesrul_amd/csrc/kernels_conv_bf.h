@@ -127,6 +127,13 @@ __device__ __forceinline__ void build_sign_lut(uint4* lut, int tid, int nthreads
   }
 
 // workgroup barrier that only waits for this wave's LDS traffic (never for VMEM)
+// a pointer known to be the same in every lane, moved to scalar registers
+__device__ __forceinline__ void* uniform_ptr(const void* p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (void*)(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -301,7 +308,8 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
   // =========================== compute state ===========================
   const int i16 = lane & 15, g4 = lane >> 4;
   bf16x8 w_hi[KS], w_lo[KS], w_b[KS];
-  int k_o[KS][2];  // LDS element offset of this lane's B fragment (m-tile 0 / 1): window invariant
+  int k_o[KS];     // LDS element offset of this lane's B fragment, m-tile 0 (m-tile 1: 16 rows further - the swizzle
+                   // mask is < 16, so the chunk position is the same): window invariant
   int k_sb[KS];    // flipout: sign word index | bit shift << 8 of the lane's 8 channels
   FwdJob J = FwdJob{-1, 0, 0, 0, -1, 0, 0, 0};
   int j_nks = 0, j_pool = 0;
@@ -311,7 +319,7 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     w_hi[ks] = w_lo[ks] = w_b[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    k_o[ks][0] = k_o[ks][1] = HALO * RS;
+    k_o[ks] = HALO * RS;
     k_sb[ks] = 0;
   }
   if (!is_loader) {
@@ -336,11 +344,8 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
           {
             const int rb = valid ? (tap - ly.pad + HALO) : HALO;
             const int cg = valid ? ((br.in_off >> 3) + c8) : 0;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-              const int rr = rb + mt * 16 + i16;
-              k_o[ks][mt] = rr * RS + ((cg ^ (rr & swm)) * 8);
-            }
+            const int rr = rb + i16;
+            k_o[ks] = rr * RS + ((cg ^ (rr & swm)) * 8);
             const int cl = valid ? c8 : 0;
             k_sb[ks] = (cl >> 2) | (((cl & 3) * 8) << 8);
           }
@@ -357,16 +362,17 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
           if constexpr (LRT) e_bb[r] = bb[r];
         }
       const TensorRef tout = A.t[br.out_t];
-      e_ohi = (u16*)tout.p;
-      e_olo = (u16*)tout.lo;
-      e_q = (u16*)A.t[br.q_t].p;
-      e_octot = tout.ctot;
+      // wave-uniform epilogue state, pinned to scalar registers (the vector file is the tight one here)
+      e_ohi = (u16*)uniform_ptr(tout.p);
+      e_olo = (u16*)uniform_ptr(tout.lo);
+      e_q = (u16*)uniform_ptr(A.t[br.q_t].p);
+      e_octot = __builtin_amdgcn_readfirstlane(tout.ctot);
       e_ooff = br.out_off + chb;
-      e_relu = br.relu;
-      e_layer = br.layer;
+      e_relu = __builtin_amdgcn_readfirstlane(br.relu);
+      e_layer = __builtin_amdgcn_readfirstlane(br.layer);
       e_lch = br.n_off + chb;
-      e_cout = ly.cout;
-      e_c4n = ly.cout_p16 >> 2;
+      e_cout = __builtin_amdgcn_readfirstlane(ly.cout);
+      e_c4n = __builtin_amdgcn_readfirstlane(ly.cout_p16 >> 2);
       e_sob = br.n_off + J.nt * 16;   // first sign_out bit of this n-tile
     }
   }
@@ -489,7 +495,7 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
           }
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
-            const int o = k_o[ks][mt];
+            const int o = k_o[ks] + mt * 16 * RS;
             const bf16x8 bh = *(const bf16x8*)&x_hi[o];
             const bf16x8 bl = *(const bf16x8*)&x_lo[o];
             acc_a[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi[ks], bh, acc_a[mt], 0, 0, 0);
@@ -510,12 +516,16 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
     stamp(k, 5);
     // ---------------- K-split reduction ----------------
     if (n_red_groups > 0) {
+      // (the lane index is made opaque here and in the epilogue: offsets derived from it are recomputed per window
+      // instead of being kept in registers across the loop - the vector file is full)
+      int rl = lane;
+      asm volatile("" : "+v"(rl));
       if (!is_loader && J.b >= 0 && J.grp >= 0 && !J.owner) {
         float* r = red + (size_t)wave * (2 * 2 * 256);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          *(f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4] = acc_a[mt];
-          if constexpr (DUAL) *(f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4] = acc_b[mt];
+          *(f32x4*)&r[(mt * 2 + 0) * 256 + rl * 4] = acc_a[mt];
+          if constexpr (DUAL) *(f32x4*)&r[(mt * 2 + 1) * 256 + rl * 4] = acc_b[mt];
         }
       }
       lds_barrier();
@@ -524,11 +534,11 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
           const float* r = red + (size_t)(wave + m) * (2 * 2 * 256);
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
-            const f32x4 pa = *(const f32x4*)&r[(mt * 2 + 0) * 256 + lane * 4];
+            const f32x4 pa = *(const f32x4*)&r[(mt * 2 + 0) * 256 + rl * 4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc_a[mt][q] += pa[q];
             if constexpr (DUAL) {
-              const f32x4 pb = *(const f32x4*)&r[(mt * 2 + 1) * 256 + lane * 4];
+              const f32x4 pb = *(const f32x4*)&r[(mt * 2 + 1) * 256 + rl * 4];
 #pragma unroll
               for (int q = 0; q < 4; ++q) acc_b[mt][q] += pb[q];
             }
@@ -540,6 +550,8 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
     // ---------------- epilogue ----------------
     if (!is_loader && J.b >= 0 && e_nv > 0 && (J.grp < 0 || J.owner) && !(A.pool_sel & 1)) {
       const int w = s * B + win_of(k);
+      int lch = e_lch, ooff = e_ooff;
+      asm volatile("" : "+v"(lch), "+v"(ooff));
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int row = mt * 16 + i16;
@@ -551,11 +563,11 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
           f32x4 eps;
           if (A.nz.use_philox_lrt) {
             const long Rg = global_row(A.cg, L, R);
-            const uint64_t idx = (uint64_t)Rg * (uint64_t)e_c4n + (uint64_t)(e_lch >> 2);
+            const uint64_t idx = (uint64_t)Rg * (uint64_t)e_c4n + (uint64_t)(lch >> 2);
             eps = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)e_layer << 8), A.nz.step,
                                  A.nz.seed);
           } else {
-            const float* e = A.nz.lrt_eps[e_layer] + (long)R * e_cout + e_lch;
+            const float* e = A.nz.lrt_eps[e_layer] + (long)R * e_cout + lch;
 #pragma unroll
             for (int r = 0; r < 4; ++r) eps[r] = (r < e_nv) ? e[r] : 0.f;
           }
@@ -583,7 +595,7 @@ __global__ __launch_bounds__((NC + NL) * 64, 4) void conv_fwd_dma_kernel(const G
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
-        const long oo = (long)R * e_octot + e_ooff;
+        const long oo = (long)R * e_octot + ooff;
         // channels beyond cout inside the 4-group are channel pads of the output tensor (zero
         // weights and bias -> exact zeros), so the whole group is always stored
         uint2 hv, lv;
