@@ -23,6 +23,9 @@ struct ConvDwPlan {
   int nsplit;             // workgroups per particle
   int has_pool;
   int no_bias;            // 1: this launch covers part of the group's tiles and another launch sums the bias gradients
+  float* slab_a;          // non-null: the workgroup stores its tiles into its own partial image (slab blockIdx.x, forward image
+  float* slab_b;          // layout) instead of adding them to the gradient images with atomics; slab_reduce_kernel sums the
+  long slab_stride;       // slabs in a fixed order
   DwTile tile[96];
 };
 
@@ -1242,15 +1245,21 @@ __global__ __launch_bounds__(NWV * 64) void conv_dw_mw_kernel(const GroupArgs A,
     const LayerDesc& ly = A.layers[br.layer];
     const int c = T.ct * 16 + jc;
     if (c >= br.cin_p) continue;
-    float* gwa = A.gw_a + A.gw_stride * s + ly.w_off;
-    float* gwb = A.gw_b + A.gw_stride * s + ly.w_off;
+    const bool slab = D.slab_a != nullptr;
+    float* gwa = (slab ? D.slab_a + D.slab_stride * blockIdx.x : A.gw_a + A.gw_stride * s) + ly.w_off;
+    float* gwb = (slab ? D.slab_b + D.slab_stride * blockIdx.x : A.gw_b + A.gw_stride * s) + ly.w_off;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = T.nt * 16 + i4 + r;
       if (n >= br.cout) continue;
       const long o = (long)(br.n_off + n) * ly.KP + (long)T.tap * ly.cin_img + c;
-      atomicAdd(gwa + o, acc_a[m][r]);
-      if constexpr (DUAL) atomicAdd(gwb + o, acc_b[m][r]);
+      if (slab) {
+        gwa[o] = acc_a[m][r];
+        if constexpr (DUAL) gwb[o] = acc_b[m][r];
+      } else {
+        atomicAdd(gwa + o, acc_a[m][r]);
+        if constexpr (DUAL) atomicAdd(gwb + o, acc_b[m][r]);
+      }
     }
   }
   if ((lane & 15) == 0 && !D.no_bias) {

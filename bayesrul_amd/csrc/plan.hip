@@ -1062,7 +1062,11 @@ static int launch_conv_dw_mw_lrt(const GroupArgs& A, const ConvDwPlan& D, int ld
   return 0;
 }
 
-static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
+// partial images ("slabs") for the per-group conv dW kernels of the Inception net: the trunk kernels' workspace and layout
+static bool conv_dw_slabs(const BnnPlan* p, int gi) { return p->slab_stride > 0 && p->d.net == BNN_NET_INCEPTION && gi < 3; }
+static int conv_dw_nsplit(const Ctx* c) { return std::max(1, std::min(c->B, 256 / std::max(1, c->S))); }
+
+static int launch_conv_dw_mw(BnnPlan* p, const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   if (em != EM_LRT) return fail(BNN_E_INVALID, "per-group conv dW: estimator %d is covered by the trunk kernels", em);
   static thread_local ConvDwPlan D, H;
@@ -1072,6 +1076,11 @@ static int launch_conv_dw_mw(const GroupArgs& A0, const LayerDesc* layers, int e
   if (A.g.L * (A.g.in_cin_p / 8) > CV_THREADS || A.g.L * (D.zw / 8) > 2 * CV_THREADS)
     return fail(BNN_E_INVALID, "conv dW staging plan exceeds the compiled unit counts");
   D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
+  if (conv_dw_slabs(p, gi)) {
+    D.slab_a = ws_f(p, p->o_slab_a[gi]);
+    D.slab_b = ws_f(p, p->o_slab_b[gi]);
+    D.slab_stride = p->slab_stride;
+  }
   const int xw16 = rup(A.g.in_cin_p, 16);
   const int xbytes = (IMG_ROWS * img_row_stride(xw16, true) * 2 + 15) & ~15;
   const int zbytes = (IMG_ROWS * img_row_stride(D.zw, true) * 2 + 15) & ~15;
@@ -1865,7 +1874,10 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
     else if (!A.g.is_dense)
-      BNN_TRY(launch_conv_dw_mw(A, p->layers, c->em, c->st, &p->prof, gi));
+      {
+      BNN_TRY(launch_conv_dw_mw(p, A, p->layers, c->em, c->st, &p->prof, gi));
+      if (gi == 0 && conv_dw_slabs(p, 0)) BNN_TRY(reduce_trunk_slabs(p, c));
+    }
     else if (A.g.n_branch == 1 && !A.g.in_bcast && A.g.br[0].cout <= 64 && (A.g.br[0].cout % 8) == 0 &&
              (A.g.br[0].cin_p % 16) == 0 && A.g.br[0].cin_real == A.g.br[0].cin_p && A.t[A.g.in_t].fmt == TF_BF16 &&
              (A.t[A.g.in_t].ctot % 8) == 0 && (A.t[A.g.br[0].out_t].ctot % 8) == 0 && A.t[A.g.br[0].out_t].fmt == TF_BF16)
@@ -1922,12 +1934,13 @@ static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c) {
   int nj = 0;
   long max_elems = 0;
   for (int which = 0; which < 3; ++which) {   // 0: slot A, 1: slot B (Flipout's dW part), 2: bias sums
-    if (which == 1 && c->em != EM_FLIPOUT) continue;
+    if (which == 1 && c->em == EM_PLAIN) continue;
+    if (which == 2 && c->em == EM_LRT) continue;   // the per-group LRT kernels add their bias sums with atomics
     SlabReduceArgs& R = J.job[nj++];
     R = SlabReduceArgs{};
     for (int g = 0; g < 3; ++g) {
       R.slab[g] = ws_f(p, which == 0 ? p->o_slab_a[g] : (which == 1 ? p->o_slab_b[g] : p->o_slab_ba[g]));
-      R.n[g] = trunk_dw_nsplit(c, g);
+      R.n[g] = c->em == EM_LRT ? conv_dw_nsplit(c) : trunk_dw_nsplit(c, g);
     }
     R.stride = which == 2 ? p->slab_bstride : p->slab_stride;
     for (int l = 0; l < 10; ++l) R.lay_end[l] = which == 2 ? p->layers[l + 1].bias_off : p->layers[l + 1].w_off;
