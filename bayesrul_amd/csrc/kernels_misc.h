@@ -114,6 +114,57 @@ __global__ void gen_signs_all_kernel(const SignGenArgs A) {
     if (q * 4 + r < words) dst[ex * words + q * 4 + r] = v[r];
 }
 
+// Everything a Flipout training step on the conv trunk generates before the weights are sampled - the weight noise, every
+// layer's sign words and the bf16 planes of the input windows - in ONE launch: three launches of a few microseconds each cost
+// more in ramp-up and drain than in work.  Block ranges: [0, b_x) weight noise, [b_x, b_sg[0]) planes of x, then one range per
+// sign entry (b_sg[e] .. b_sg[e + 1]).  The streams are those of gen_eps_w_kernel / gen_signs_all_kernel.
+struct StepInputsArgs {
+  float* eps; long P; int S; uint64_t eps_seed; uint32_t step;
+  const float* x; u16* xp[4]; long rows; int L, F;
+  SignGenArgs sg;
+  unsigned b_x;
+  unsigned b_sg[2 * BNN_MAX_LAYERS + 1];
+};
+__device__ __forceinline__ void x_planes4_dev(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F, long idx);
+
+__global__ __launch_bounds__(256) void step_inputs_kernel(const StepInputsArgs A) {
+  const unsigned blk = blockIdx.x;
+  if (blk < A.b_x) {
+    const long n4 = (A.P + 3) >> 2;
+    const long idx = (long)blk * 256 + threadIdx.x;
+    if (idx >= n4 * A.S) return;
+    const int s = (int)(idx / n4);
+    const long q = idx - (long)s * n4;
+    const f32x4 z = philox_normal4((uint32_t)q, (uint32_t)s, NK_EPSW, A.step, A.eps_seed);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (q * 4 + r < A.P) A.eps[(long)s * A.P + q * 4 + r] = z[r];
+    return;
+  }
+  if (blk < A.b_sg[0]) {
+    x_planes4_dev(A.x, A.xp[0], A.xp[1], A.xp[2], A.xp[3], A.rows, A.L, A.F, (long)(blk - A.b_x) * 256 + threadIdx.x);
+    return;
+  }
+  int e = 0;
+  for (int k = 1; k < A.sg.n; ++k)
+    if (blk >= A.b_sg[k]) e = k;
+  const int words = A.sg.words[e];
+  const int w4 = (words + 3) >> 2;
+  const long idx = (long)(blk - A.b_sg[e]) * 256 + threadIdx.x;
+  if (idx >= (long)A.sg.S * A.sg.B * w4) return;
+  const int q = (int)(idx % w4);
+  const long ex = idx / w4;
+  const int s = (int)(ex / A.sg.B), b = (int)(ex - (long)s * A.sg.B);
+  const uint32_t gex = (uint32_t)(A.sg.goff + b);
+  const uint4 u = philox4x32_10(gex * (uint32_t)w4 + (uint32_t)q, (uint32_t)s, A.sg.kind[e] | ((uint32_t)A.sg.layer[e] << 8),
+                                A.sg.step, (uint32_t)A.sg.seed, (uint32_t)(A.sg.seed >> 32));
+  const uint32_t v[4] = {u.x, u.y, u.z, u.w};
+  uint32_t* dst = A.sg.dst[e];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (q * 4 + r < words) dst[ex * words + q * 4 + r] = v[r];
+}
+
 // floats (+1/-1) [rows][C] -> packed bits (1 = negative)
 __global__ void pack_signs_kernel(const float* src, uint32_t* dst, long rows, int C, int words) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -468,8 +468,7 @@ __global__ __launch_bounds__(TR_THREADS) void trunk_fwd_kernel(const TrunkArgs A
 
 // bf16 hi/lo planes [rows][32] of the raw fp32 windows and of their MaxPool1d(3,1,1) copy (block 1's pooled
 // branch, inception.py:41-46); channel pads zero.  rows = B * L, pooling stays inside a window.
-__global__ void x_planes4_kernel(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void x_planes4_dev(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F, long idx) {
   if (idx >= rows * 32) return;
   const long r = idx >> 5;
   const int c = (int)(idx & 31);
@@ -486,4 +485,7 @@ __global__ void x_planes4_kernel(const float* x, u16* hi, u16* lo, u16* phi, u16
   lo[idx] = f2bf(v - bf2f(h));
   phi[idx] = ph;
   plo[idx] = f2bf(p - bf2f(ph));
+}
+__global__ void x_planes4_kernel(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F) {
+  x_planes4_dev(x, hi, lo, phi, plo, rows, L, F, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }

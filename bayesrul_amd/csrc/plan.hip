@@ -596,6 +596,8 @@ struct Ctx {
   NoiseRefs nz{};
   int s_base = 0;  // particle offset for noise streams (predict chunks)
   bool x_planes_ready = false;   // predictive pass, chunks after the first: the planes of x are already in the workspace
+  const float* fuse_x = nullptr; // training step on the trunk path: prepare_noise may generate the planes of these windows in
+                                 // the launch that generates the noise (step_inputs_kernel)
   bool grads_zeroed = false;     // the gradient images need no fill in do_backward (done earlier, or every element is stored)
   bool last_fused = false;       // Inception trunk path: the last layer Linear(64, 2) runs inside the fin / head kernels
   bool head_fused = false;       // bnn_elbo_step on the fused Linear-net path: the head runs inside the backward's first kernel
@@ -643,6 +645,8 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
   c->nz.step = step;
   const int S = c->S, B = c->B;
   const bool need_eps = c->mode != BNN_MODE_LRT;
+  // one launch for weight noise + sign words + planes of x when all of them are generated here (nothing injected)
+  const bool fused = c->fuse_x && c->mode == BNN_MODE_FLIPOUT && !g_dry && !(nz && (nz->eps_w || nz->sign_in || nz->sign_out));
   if (need_eps) {
     if (nz && nz->eps_w) {
       c->eps_w = nz->eps_w;
@@ -650,7 +654,8 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
       float* e = ws_f(p, p->o_eps);
       const long n = ((p->P + 3) / 4) * S;
       // particle offset is folded into the step word for predict chunks
-      gen_eps_w_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(e, p->P, S, seed + 0x9E37ull * c->s_base, step);
+      if (!fused)
+        gen_eps_w_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->st>>>(e, p->P, S, seed + 0x9E37ull * c->s_base, step);
       c->eps_w = e;
     }
   }
@@ -696,7 +701,27 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
         SG.n++;
       }
     }
-    if (SG.n > 0) {
+    if (fused) {
+      static thread_local StepInputsArgs SI;
+      SI = StepInputsArgs{};
+      SI.eps = ws_f(p, p->o_eps); SI.P = p->P; SI.S = S; SI.eps_seed = seed + 0x9E37ull * c->s_base; SI.step = step;
+      const int L = p->d.win_length;
+      const size_t plane = (size_t)p->d.max_batch * L * 32;
+      u16* xp = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
+      SI.x = c->fuse_x; SI.rows = (long)B * L; SI.L = L; SI.F = p->d.n_features;
+      for (int k = 0; k < 4; ++k) SI.xp[k] = xp + k * plane;
+      SI.sg = SG;
+      unsigned nb = (unsigned)((((p->P + 3) / 4) * S + 255) / 256);
+      SI.b_x = nb;
+      nb += (unsigned)((SI.rows * 32 + 255) / 256);
+      for (int e = 0; e < SG.n; ++e) {
+        SI.b_sg[e] = nb;
+        nb += (unsigned)((ex * ((SG.words[e] + 3) / 4) + 255) / 256);
+      }
+      SI.b_sg[SG.n] = nb;
+      step_inputs_kernel<<<dim3(nb), dim3(256), 0, c->st>>>(SI);
+      c->x_planes_ready = true;
+    } else if (SG.n > 0) {
       const long n = ex * maxw4;
       gen_signs_all_kernel<<<dim3((unsigned)((n + 255) / 256), SG.n), dim3(256), 0, c->st>>>(SG);
     }
@@ -2140,6 +2165,7 @@ extern "C" int bnn_elbo_step(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* n
   Ctx c;
   BNN_TRY(make_ctx(p, a, nz, stream, true, &c));
   if (!a->with_obs) return fail(BNN_E_INVALID, "bnn_elbo_step needs with_obs = 1");
+  if (trunk_ok(p, &c)) c.fuse_x = a->x;
   BNN_TRY(prepare_noise(p, a, nz, &c));
   BNN_TRY(do_sample(p, a, &c));
   BNN_TRY(do_forward(p, a, &c, a->x));
