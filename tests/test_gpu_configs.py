@@ -142,3 +142,28 @@ def test_full_size_predictive_pass_s100():
     assert torch.allclose(b[1] ** 2, b[2] + b[3], rtol=1e-5, atol=1e-9)
     assert torch.allclose(b[0], a[0], rtol=1e-3, atol=1e-4)
     assert torch.allclose(b[1], a[1], rtol=5e-3, atol=1e-4)
+
+
+def test_generated_noise_step_equals_replayed_export_bf16x3():
+    """The training step on the fused trunk generates weight noise, sign words and the planes of x in one launch
+    (step_inputs_kernel).  The same step with the exported noise injected goes through the separate kernels
+    (pack_signs / x_planes4): both must give the same loss and gradient bit for bit, and the LRT conv path (partial
+    images + fixed-order reduction for the conv dW) must agree with its own replay to fp32 rounding (its dense layers
+    still add with atomics)."""
+    S, B = 3, 9
+    for mode, exact in (("flipout", True), ("lrt", False)):
+        ps, qs, lr = HYP[mode]
+        eng = _engine("inception", mode, "bf16x3", S, B)
+        eng.init_params(R.init_mu0("inception", 0, torch.float64), qs * 20.0)
+        x, y = synth_batch(B)
+        r1 = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, seed=11, step=4, keep=True)
+        g1 = eng.grad.clone()
+        inj = eng.export_noise(B, S, seed=11, step=4)
+        r2 = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, inj, keep=True)
+        g2 = eng.grad.clone()
+        if exact:
+            assert float(r1[0]) == float(r2[0]), (float(r1[0]), float(r2[0]))
+            assert torch.equal(g1, g2)
+        else:
+            assert abs(float(r1[0]) - float(r2[0])) <= 1e-6 * abs(float(r1[0]))
+            assert rel_l2(g1.cpu(), g2.cpu()) < 1e-5
