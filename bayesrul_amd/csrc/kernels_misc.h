@@ -120,6 +120,7 @@ __global__ void gen_signs_all_kernel(const SignGenArgs A) {
 // sign entry (b_sg[e] .. b_sg[e + 1]).  The streams are those of gen_eps_w_kernel / gen_signs_all_kernel.
 struct StepInputsArgs {
   float* eps; long P; int S; uint64_t eps_seed; uint32_t step;
+  float* rad_r; int n_sites;   // radial guide: the S * n_sites radial distances ride on the last weight-noise block
   const float* x; u16* xp[4]; long rows; int L, F;
   SignGenArgs sg;
   unsigned b_x;
@@ -132,6 +133,14 @@ __global__ __launch_bounds__(256) void step_inputs_kernel(const StepInputsArgs A
   if (blk < A.b_x) {
     const long n4 = (A.P + 3) >> 2;
     const long idx = (long)blk * 256 + threadIdx.x;
+    if (A.rad_r && blk == A.b_x - 1) {
+      // (an extra block appended to the weight-noise range)
+      for (int i = threadIdx.x; i < A.n_sites * A.S; i += 256) {
+        const int rs = i / A.n_sites, site = i - rs * A.n_sites;
+        A.rad_r[i] = philox_normal4((uint32_t)site, (uint32_t)rs, NK_RADIAL_R, A.step, A.eps_seed)[0];
+      }
+      return;
+    }
     if (idx >= n4 * A.S) return;
     const int s = (int)(idx / n4);
     const long q = idx - (long)s * n4;

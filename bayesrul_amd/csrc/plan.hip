@@ -646,7 +646,35 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
   const int S = c->S, B = c->B;
   const bool need_eps = c->mode != BNN_MODE_LRT;
   // one launch for weight noise + sign words + planes of x when all of them are generated here (nothing injected)
-  const bool fused = c->fuse_x && c->mode == BNN_MODE_FLIPOUT && !g_dry && !(nz && (nz->eps_w || nz->sign_in || nz->sign_out));
+  const bool fused_fo = c->fuse_x && c->mode == BNN_MODE_FLIPOUT && !g_dry && !(nz && (nz->eps_w || nz->sign_in || nz->sign_out));
+  const bool fused_rad = c->fuse_x && c->radial && !g_dry && !(nz && (nz->eps_w || nz->radial_r));
+  const bool fused = fused_fo || fused_rad;
+  static thread_local StepInputsArgs SI;
+  auto fill_inputs = [&](const SignGenArgs* SG, long ex) {
+    SI = StepInputsArgs{};
+    SI.eps = ws_f(p, p->o_eps); SI.P = p->P; SI.S = S; SI.eps_seed = seed + 0x9E37ull * c->s_base; SI.step = step;
+    const int L = p->d.win_length;
+    const size_t plane = (size_t)p->d.max_batch * L * 32;
+    u16* xp = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
+    SI.x = c->fuse_x; SI.rows = (long)B * L; SI.L = L; SI.F = p->d.n_features;
+    for (int k = 0; k < 4; ++k) SI.xp[k] = xp + k * plane;
+    unsigned nb = (unsigned)((((p->P + 3) / 4) * S + 255) / 256);
+    if (fused_rad) {
+      SI.rad_r = ws_f(p, p->o_radr); SI.n_sites = p->n_sites;
+      nb += 1;
+    }
+    SI.b_x = nb;
+    nb += (unsigned)((SI.rows * 32 + 255) / 256);
+    if (SG) SI.sg = *SG;
+    for (int e = 0; e < SI.sg.n; ++e) {
+      SI.b_sg[e] = nb;
+      nb += (unsigned)((ex * ((SI.sg.words[e] + 3) / 4) + 255) / 256);
+    }
+    SI.b_sg[SI.sg.n] = nb;
+    if (SI.sg.n == 0) SI.b_sg[0] = nb;
+    step_inputs_kernel<<<dim3(nb), dim3(256), 0, c->st>>>(SI);
+    c->x_planes_ready = true;
+  };
   if (need_eps) {
     if (nz && nz->eps_w) {
       c->eps_w = nz->eps_w;
@@ -664,7 +692,10 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
       c->rad_r = nz->radial_r;
     } else {
       float* r = ws_f(p, p->o_radr);
-      gen_radial_r_kernel<<<dim3((S * p->n_sites + 255) / 256), dim3(256), 0, c->st>>>(r, p->n_sites, S, seed + 0x9E37ull * c->s_base, step);
+      if (fused_rad)
+        fill_inputs(nullptr, 0);   // weight noise + radial distances + planes of x: one launch
+      else
+        gen_radial_r_kernel<<<dim3((S * p->n_sites + 255) / 256), dim3(256), 0, c->st>>>(r, p->n_sites, S, seed + 0x9E37ull * c->s_base, step);
       c->rad_r = r;
     }
     site_norm_kernel<<<dim3(S * p->n_sites), dim3(256), 0, c->st>>>(c->eps_w, p->P, p->ptab, ws_f(p, p->o_norms));
@@ -701,26 +732,8 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
         SG.n++;
       }
     }
-    if (fused) {
-      static thread_local StepInputsArgs SI;
-      SI = StepInputsArgs{};
-      SI.eps = ws_f(p, p->o_eps); SI.P = p->P; SI.S = S; SI.eps_seed = seed + 0x9E37ull * c->s_base; SI.step = step;
-      const int L = p->d.win_length;
-      const size_t plane = (size_t)p->d.max_batch * L * 32;
-      u16* xp = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
-      SI.x = c->fuse_x; SI.rows = (long)B * L; SI.L = L; SI.F = p->d.n_features;
-      for (int k = 0; k < 4; ++k) SI.xp[k] = xp + k * plane;
-      SI.sg = SG;
-      unsigned nb = (unsigned)((((p->P + 3) / 4) * S + 255) / 256);
-      SI.b_x = nb;
-      nb += (unsigned)((SI.rows * 32 + 255) / 256);
-      for (int e = 0; e < SG.n; ++e) {
-        SI.b_sg[e] = nb;
-        nb += (unsigned)((ex * ((SG.words[e] + 3) / 4) + 255) / 256);
-      }
-      SI.b_sg[SG.n] = nb;
-      step_inputs_kernel<<<dim3(nb), dim3(256), 0, c->st>>>(SI);
-      c->x_planes_ready = true;
+    if (fused_fo) {
+      fill_inputs(&SG, ex);
     } else if (SG.n > 0) {
       const long n = ex * maxw4;
       gen_signs_all_kernel<<<dim3((unsigned)((n + 255) / 256), SG.n), dim3(256), 0, c->st>>>(SG);

@@ -151,7 +151,7 @@ def test_generated_noise_step_equals_replayed_export_bf16x3():
     images + fixed-order reduction for the conv dW) must agree with its own replay to fp32 rounding (its dense layers
     still add with atomics)."""
     S, B = 3, 9
-    for mode, exact in (("flipout", True), ("lrt", False)):
+    for mode, exact in (("flipout", True), ("radial", True), ("lrt", False)):
         ps, qs, lr = HYP[mode]
         eng = _engine("inception", mode, "bf16x3", S, B)
         eng.init_params(R.init_mu0("inception", 0, torch.float64), qs * 20.0)
