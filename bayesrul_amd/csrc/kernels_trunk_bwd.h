@@ -295,7 +295,18 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
                 if constexpr (FO) bs[ks][mt] = *(const bf16x8*)(bp + TX_P2);
               }
             }
+            // the ReLU mask of the tile's outputs (mask byte -> AND masks: two dependent LDS reads) is fetched with the
+            // operands, not after the MFMAs: this role is one wave per SIMD and its per-tile latency chain is the step
+            const int och = (half * 4 + j) * 16 + 4 * g4;   // MID channel
+            uint2 mk[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const uint32_t mb = *(const unsigned char*)(dsl + (mt * 16 + i16) * 16 + (och >> 3));
+              mk[mt] = *(const uint2*)(smem + TX_O_MLUT + ((mb >> (och & 4)) & 15u) * 8);
+            }
             __builtin_amdgcn_sched_barrier(0);   // reads first, then the MFMAs
+            f32x4 accb[2];   // Flipout: the perturbation path accumulates on its own (two dependent chains per m-tile, not one)
+            accb[0] = accb[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
               if (ks >= NKS) break;
@@ -305,11 +316,16 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
 #pragma unroll
               for (int mt = 0; mt < 2; ++mt) {
                 acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bz[ks][mt], acc[mt], 0, 0, 0);
-                if constexpr (FO) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, bs[ks][mt], acc[mt], 0, 0, 0);
+                if constexpr (FO) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, bs[ks][mt], accb[mt], 0, 0, 0);
               }
             }
+            if constexpr (FO) {
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][r] += accb[mt][r];
+            }
             // epilogue: mask with [MID > 0], dz -> LDS (+ s_out copy) and HBM
-            const int och = (half * 4 + j) * 16 + 4 * g4;   // MID channel
             const int oly = half == 0 ? 5 : 7;              // the 1x1 layer that produced these MID channels
             uint32_t so = 0;
             if constexpr (FO) {
@@ -320,11 +336,9 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
             for (int mt = 0; mt < 2; ++mt) {
               const int row = mt * 16 + i16;
               if (row < L) {
-                const uint32_t mb = *(const unsigned char*)(dsl + row * 16 + (och >> 3));
-                const uint2 mk = *(const uint2*)(smem + TX_O_MLUT + ((mb >> (och & 4)) & 15u) * 8);
                 uint2 d = make_uint2(cvt_pk(acc[mt][0], acc[mt][1]), cvt_pk(acc[mt][2], acc[mt][3]));
-                d.x &= mk.x;
-                d.y &= mk.y;
+                d.x &= mk[mt].x;
+                d.y &= mk[mt].y;
                 const int o = (row + HALO) * TR_RSB + och * 2;
                 *(uint2*)(dzm + o) = d;
                 if constexpr (FO) {
@@ -379,6 +393,16 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         // all operand reads of an m-tile are issued before its MFMAs (one LDS latency per m-tile, not one per k-step)
         bf16x8 w2[6];
         __builtin_amdgcn_sched_barrier(0);
+        // the ReLU masks and pool codes of the tile's outputs are fetched here, ahead of the MFMAs (dependent LDS reads)
+        uint2 mk[2];
+        uint32_t code[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int row = mt * 16 + i16;
+          const uint32_t mb = *(const unsigned char*)(dsl + TX_PD + row * 16 + (och >> 3));
+          mk[mt] = *(const uint2*)(smem + TX_O_MLUT + ((mb >> (och & 4)) & 15u) * 8);
+          code[mt] = row < L ? *(const unsigned char*)(dsl + 2 * TX_PD + row * 32 + (och >> 2)) : 0x55u;
+        }
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
           w2[q] = wb[q];
@@ -423,10 +447,9 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         for (int mt = 0; mt < 2; ++mt) {
           const int row = mt * 16 + i16;
           v[mt] = acc[mt];
-          const uint32_t code = row < L ? *(const unsigned char*)(dsl + 2 * TX_PD + row * 32 + (och >> 2)) : 0x55u;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const uint32_t cd = (code >> (2 * r)) & 3u;
+            const uint32_t cd = (code[mt] >> (2 * r)) & 3u;
             const float g = row < L ? accp[mt][r] : 0.f;
             v[mt][r] += cd == 1u ? g : 0.f;
             up[mt][r] = cd == 0u ? g : 0.f;
@@ -445,11 +468,9 @@ __global__ __launch_bounds__(TX_THREADS) void trunk_dx_kernel(const TrunkDxArgs 
         for (int mt = 0; mt < 2; ++mt) {
           const int row = mt * 16 + i16;
           if (row < L) {
-            const uint32_t mb = *(const unsigned char*)(dsl + TX_PD + row * 16 + (och >> 3));
-            const uint2 mk = *(const uint2*)(smem + TX_O_MLUT + ((mb >> (och & 4)) & 15u) * 8);
             uint2 d = make_uint2(cvt_pk(v[mt][0], v[mt][1]), cvt_pk(v[mt][2], v[mt][3]));
-            d.x &= mk.x;
-            d.y &= mk.y;
+            d.x &= mk[mt].x;
+            d.y &= mk[mt].y;
             if constexpr (!(TX_ABL & 1)) *(uint2*)((char*)A.g_act1 + ((R0 + (unsigned)row) * 256u + (unsigned)(och * 2))) = d;
             else asm volatile("" ::"v"(d.x), "v"(d.y));
           }
