@@ -215,20 +215,48 @@ __global__ void export_lrt_eps_kernel(float* dst, long rows, int cout, int cout_
 // ------------------------------------------------------------------------------------------
 // radial: per (particle, site) L2 norm of eps  (guides/radial.py:38)
 // ------------------------------------------------------------------------------------------
-__global__ void site_norm_kernel(const float* eps_w, long P, ParamTable T, float* norms) {
-  const int site = blockIdx.x % T.n_sites, s = blockIdx.x / T.n_sites;
-  const float* e = eps_w + (long)s * P + T.site[site].off;
+// Two launches: partial sums of squares over chunks of SN_CHUNK elements (a site of 153,600 elements as ONE workgroup was a
+// 150 us chain of dependent loads at S = 20: 15 % of the radial step), then one thread per (particle, site) adds the
+// chunks in order (fixed order: reproducible).
+enum { SN_CHUNK = 8192 };
+struct SiteChunks {
+  int total;                       // chunks per particle
+  int start[BNN_MAX_SITES + 1];    // first chunk of site i
+};
+
+__global__ __launch_bounds__(256) void site_norm_part_kernel(const float* eps_w, long P, ParamTable T, SiteChunks C, double* part) {
+  const int s = blockIdx.x / C.total, ch = blockIdx.x - s * C.total;
+  int site = 0;
+  for (int i = 1; i < T.n_sites; ++i)
+    if (ch >= C.start[i]) site = i;
+  const long k0 = (long)(ch - C.start[site]) * SN_CHUNK;
+  const long n = min((long)SN_CHUNK, T.site[site].numel - k0);
+  const float* e = eps_w + (long)s * P + T.site[site].off + k0;
   double acc = 0.0;
-  for (long k = threadIdx.x; k < T.site[site].numel; k += blockDim.x) acc += (double)e[k] * (double)e[k];
+  for (int j0 = 0; j0 < SN_CHUNK / 256; j0 += 8) {   // 8 loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long k = (long)(j0 + u) * 256 + threadIdx.x;
+      v[u] = k < n ? e[k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (double)v[u] * (double)v[u];
+  }
   __shared__ double red[4];
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0;
-    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k];
-    norms[s * T.n_sites + site] = (float)sqrt(t);
-  }
+  if (threadIdx.x == 0) part[(long)s * C.total + ch] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void site_norm_fin_kernel(const double* part, ParamTable T, SiteChunks C, int S, float* norms) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * T.n_sites) return;
+  const int s = i / T.n_sites, site = i - s * T.n_sites;
+  double t = 0.0;
+  for (int c = C.start[site]; c < C.start[site + 1]; ++c) t += part[(long)s * C.total + c];
+  norms[i] = (float)sqrt(t);
 }
 
 // ------------------------------------------------------------------------------------------

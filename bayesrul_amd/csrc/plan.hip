@@ -144,7 +144,7 @@ struct BnnPlan {
   long slab_stride = 0;
   int slab_bstride = 0;
   size_t o_layers, o_a_hi, o_a_lo, o_b, o_at, o_bt, o_bias_a, o_bias_b, o_gw_a, o_gw_b, o_gb_a, o_gb_b, o_eps, o_radr,
-      o_norms, o_sign_in, o_sign_out, o_acc, o_scal, o_preds, o_poolgrad, o_xplanes, o_amax, o_tens;
+      o_norms, o_norm_part, o_sign_in, o_sign_out, o_acc, o_scal, o_preds, o_poolgrad, o_xplanes, o_amax, o_tens;
   size_t elem = 4;
   bool bound = false;
   BnnBuffers bufs{};
@@ -390,6 +390,7 @@ static void layout_workspace(BnnPlan* p) {
   p->o_eps = take((size_t)S * p->P * 4);
   p->o_radr = take((size_t)S * p->n_sites * 4);
   p->o_norms = take((size_t)S * p->n_sites * 4);
+  p->o_norm_part = take((size_t)S * (p->n_sites + p->P / SN_CHUNK + 1) * 8);   // radial: partial sums of squares per chunk
   p->o_sign_in = take((size_t)cap * p->sign_in_words_total * 4);
   p->o_sign_out = take((size_t)cap * p->sign_out_words_total * 4);
   p->o_acc = take(sizeof(double) * 2 * (S + 1));
@@ -698,7 +699,14 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
         gen_radial_r_kernel<<<dim3((S * p->n_sites + 255) / 256), dim3(256), 0, c->st>>>(r, p->n_sites, S, seed + 0x9E37ull * c->s_base, step);
       c->rad_r = r;
     }
-    site_norm_kernel<<<dim3(S * p->n_sites), dim3(256), 0, c->st>>>(c->eps_w, p->P, p->ptab, ws_f(p, p->o_norms));
+    {
+      SiteChunks C{};
+      for (int i = 0; i < p->n_sites; ++i) C.start[i + 1] = C.start[i] + (int)((p->ptab.site[i].numel + SN_CHUNK - 1) / SN_CHUNK);
+      C.total = C.start[p->n_sites];
+      double* part = (double*)((char*)p->bufs.workspace + p->o_norm_part);
+      site_norm_part_kernel<<<dim3(S * C.total), dim3(256), 0, c->st>>>(c->eps_w, p->P, p->ptab, C, part);
+      site_norm_fin_kernel<<<dim3((S * p->n_sites + 255) / 256), dim3(256), 0, c->st>>>(part, p->ptab, C, S, ws_f(p, p->o_norms));
+    }
   }
   // layer sign arrays live back to back: layer i at (sign_*_off * S*B) words
   uint32_t* si = (uint32_t*)ws_f(p, p->o_sign_in);
