@@ -280,6 +280,7 @@ struct PrepArgs {
   int bias_total;
   double* kl_acc;       // [S] (radial) or [1]
   float prior_loc, prior_scale;
+  long skip_lo, skip_hi; // elements [skip_lo, skip_hi) of the flat buffers are handled by prep_flat_dense_kernel (0, 0: none)
 };
 
 template <class P>
@@ -294,8 +295,9 @@ __device__ __forceinline__ void put_img(void* hi, void* lo, long idx, float v) {
 }
 
 template <class P>
-__global__ void prep_weights_kernel(const PrepArgs A) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void prep_weights_body(const PrepArgs& A, unsigned bid) {
+  long e = (long)bid * blockDim.x + threadIdx.x;
+  if (e >= A.skip_lo) e += A.skip_hi - A.skip_lo;   // the grid covers the elements outside the skipped range only
   const bool live = e < A.T.P;
   const int lane = threadIdx.x & 63;
   __shared__ double red[16];   // up to 1024 threads per workgroup
@@ -347,20 +349,23 @@ __global__ void prep_weights_kernel(const PrepArgs A) {
     }
   }
   if (A.mode != 1) {
-    // the particles' noise values of this element: loads of four particles in flight (a load per iteration followed by
-    // its dependent stores made the kernel latency-bound: S round trips per thread)
-    for (int s0 = 0; s0 < A.S; s0 += 4) {
-      float ev[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {1.f, 1.f, 1.f, 1.f};
+    // the particles' noise values of this element: loads of up to 16 particles in flight (a load per iteration followed
+    // by its dependent stores made the kernel latency-bound: S round trips per thread)
+    constexpr int NB = 16;   // particles per batch of loads
+    for (int s0 = 0; s0 < A.S; s0 += NB) {
+      float ev[NB], rv[NB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int s = min(s0 + u, A.S - 1);
+        ev[u] = 0.f;
+        rv[u] = 1.f;
         if (live) {
           ev[u] = A.eps_w[(long)s * A.T.P + e];
           if (radial) rv[u] = A.rad_r[s * A.T.n_sites + si] / A.norms[s * A.T.n_sites + si];
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NB; ++u) {
       const int s = s0 + u;
       if (s >= A.S) break;
       double term = 0.0;
@@ -411,6 +416,134 @@ __global__ void prep_weights_kernel(const PrepArgs A) {
       atomicAdd(A.kl_acc, tt);
     }
   }
+}
+
+template <class P>
+__global__ void prep_weights_kernel(const PrepArgs A) {
+  prep_weights_body<P>(A, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same for the weights of a dense layer that follows nn.Flatten of [C][L] activations kept as [L][C] rows (the Inception
+// net's Linear(2400, 64): 80 % of its parameters), bf16 plans, every estimator but LRT.  In the canonical order (cout, c, l)
+// a thread per element stores 2 bytes at stride 2 C in the forward image [cout][l C + c] and at stride 2 KPt in the
+// transposed one [l C + c][cout]: 64 write requests per wave store, which - not bytes - is what bounded the one-thread-per-
+// element kernel.  Here a workgroup takes a (16 cout, 8 c, all l) tile of one particle: coalesced runs of 8 L floats in,
+// through LDS, 16-byte pieces out (8 channels of a forward row, 8 couts of a transposed row).
+// grid.x = (cout / 16) * (C / 8) tiles, grid.y = particles (+ 1 for Flipout: the shared mean images and the KL).
+// ------------------------------------------------------------------------------------------
+// C, Lw are template parameters: the index arithmetic is divisions by them (by a run-time value: ~40 instructions each,
+// and the kernel was bound by exactly that).
+enum { PF_TN = 16, PF_TC = 8 };
+template <int C, int Lw>
+__device__ __forceinline__ void prep_flat_dense_body(const PrepArgs& A, int layer_id, int site, int tile_blk, int s) {
+  extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+  const LayerDesc ly = A.layers[layer_id];
+  constexpr int ncg = C / PF_TC;
+  const int ng = tile_blk / ncg, cg = tile_blk - ng * ncg;
+  const int n0 = ng * PF_TN, c0 = cg * PF_TC;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool mean_pass = (A.mode == 2 && s == A.S);
+  const bool radial = (A.mode == 3);
+  const bool want_kl = mean_pass || (A.mode == 0 && s == 0);
+  constexpr int run = PF_TC * Lw, tile = PF_TN * run;
+  u16* th = (u16*)pf_smem;
+  u16* tl = th + tile;
+  const long off = A.T.site[site].off;
+  float rr = 1.f;
+  if (radial) rr = A.rad_r[s * A.T.n_sites + site] / A.norms[s * A.T.n_sites + site];
+  const long so = mean_pass ? 0 : (long)s * A.T.P;
+  double acc = 0.0;
+  // all loads of the tile first (PF_IT iterations of 256 elements, L <= 32), then the arithmetic: a load per iteration
+  // followed by its dependent LDS stores would be PF_IT round trips
+  constexpr int PF_IT = (tile + 255) / 256;
+  float mu_r[PF_IT], rho_r[PF_IT], eps_r[PF_IT];
+#pragma unroll
+  for (int it = 0; it < PF_IT; ++it) {
+    const int idx = min(it * 256 + tid, tile - 1);
+    const int nl = idx / run, rem = idx - nl * run;
+    const int cl = rem / Lw, l = rem - cl * Lw;
+    const long e = off + (long)(n0 + nl) * ly.cin + (long)(c0 + cl) * Lw + l;
+    mu_r[it] = A.mu[e];
+    rho_r[it] = A.rho[e];
+    eps_r[it] = mean_pass ? 0.f : A.eps_w[so + e];
+  }
+#pragma unroll
+  for (int it = 0; it < PF_IT; ++it) {
+    const int idx = it * 256 + tid;
+    if (idx >= tile) break;
+    const int nl = idx / run, rem = idx - nl * run;
+    const int cl = rem / Lw, l = rem - cl * Lw;
+    const float mu = mu_r[it], rho = rho_r[it];
+    const float sigma = expf(rho);
+    float v = mu;
+    if (!mean_pass) {
+      float eps = eps_r[it];
+      if (radial) eps = eps * rr;
+      const float dw = sigma * eps;
+      const float w = mu + dw;
+      v = A.mode == 2 ? dw : w;
+      if (radial) {
+        const float zp = (w - A.prior_loc) / A.prior_scale;
+        acc += -0.5 * (double)eps * (double)eps - (double)rho + 0.5 * (double)zp * (double)zp + (double)logf(A.prior_scale);
+      }
+    }
+    if (want_kl) {
+      const float vr = (sigma / A.prior_scale) * (sigma / A.prior_scale);
+      const float t1 = ((mu - A.prior_loc) / A.prior_scale) * ((mu - A.prior_loc) / A.prior_scale);
+      acc += 0.5 * ((double)vr + (double)t1 - 1.0 - (double)logf(vr));
+    }
+    const u16 h = f2bf(v);
+    const int o = nl * run + l * PF_TC + cl;
+    th[o] = h;
+    tl[o] = f2bf(v - bf2f(h));
+  }
+  __syncthreads();
+  // destinations: Flipout particle pass -> slot B (single bf16); mean pass -> the shared slot A; normal / radial -> slot A of s
+  u16 *d_hi, *d_lo, *d_t;
+  if (A.mode == 2 && !mean_pass) {
+    d_hi = (u16*)A.b + A.slot_stride * s; d_lo = nullptr; d_t = (u16*)A.bt + A.slott_stride * s;
+  } else if (mean_pass) {
+    d_hi = (u16*)A.a_hi; d_lo = (u16*)A.a_lo; d_t = (u16*)A.at;
+  } else {
+    d_hi = (u16*)A.a_hi + A.slot_stride * s; d_lo = (u16*)A.a_lo + A.slot_stride * s; d_t = (u16*)A.at + A.slott_stride * s;
+  }
+  for (int u = tid; u < PF_TN * Lw; u += 256) {
+    const int nl = u / Lw, l = u - nl * Lw;
+    const long fi = ly.w_off + (long)(n0 + nl) * ly.KP + (long)l * C + c0;
+    *(uint4*)(d_hi + fi) = *(const uint4*)(th + nl * run + l * PF_TC);
+    if (d_lo) *(uint4*)(d_lo + fi) = *(const uint4*)(tl + nl * run + l * PF_TC);
+  }
+  if (A.want_t) {
+    for (int u = tid; u < run * 2; u += 256) {
+      const int half = u & 1, q = u >> 1;   // q = l * TC + cl
+      const int l = q / PF_TC, cl = q - l * PF_TC;
+      uint32_t w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int na = half * 8 + 2 * j;
+        w[j] = (uint32_t)th[na * run + q] | ((uint32_t)th[(na + 1) * run + q] << 16);
+      }
+      const long ti = ly.wt_off + (long)(l * C + c0 + cl) * ly.KPt + n0 + half * 8;
+      *(uint4*)(d_t + ti) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  if (want_kl || radial) {
+    __shared__ double red[4];
+    const double t = wave_sum_d(acc);
+    if (lane == 0) red[tid >> 6] = t;
+    __syncthreads();
+    if (tid == 0) atomicAdd(A.kl_acc + (radial ? s : 0), (red[0] + red[1]) + (red[2] + red[3]));
+  }
+}
+
+// One launch for both: workgroups [0, n_tiles * ny) are (tile, particle) pairs of the wide dense layer, the rest walk the
+// remaining elements one thread each (two launches of ~15 us of mostly latency each were slower than the single
+// one-thread-per-element launch they replaced; side by side they are not).
+template <int C, int Lw>
+__global__ __launch_bounds__(256) void prep_fused_kernel(const PrepArgs A, int layer_id, int site, unsigned n_tiles, unsigned ny) {
+  if (blockIdx.x < n_tiles * ny) prep_flat_dense_body<C, Lw>(A, layer_id, site, (int)(blockIdx.x % n_tiles), (int)(blockIdx.x / n_tiles));
+  else prep_weights_body<PrecBF>(A, blockIdx.x - n_tiles * ny);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -792,8 +792,32 @@ static int do_sample(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
   A.kl_acc = (double*)(w + p->o_acc);
   A.prior_loc = (float)a->prior_loc;
   A.prior_scale = (float)a->prior_scale;
-  const unsigned grid = (unsigned)((p->P + 1023) / 1024);   // 1024-thread workgroups: four times fewer fp64 atomics on the KL sum
   ProfScope ps_(&p->prof, PK_SAMPLE, 0, c->st);
+  // the wide dense layer behind nn.Flatten goes through the tile kernel (16-byte image stores instead of 2-byte ones)
+  int flat_layer = -1;
+  if (p->d.prec == BNN_PREC_BF16X3 && c->mode != BNN_MODE_LRT)
+    for (int i = 0; i < p->n_layers; ++i) {
+      const LayerDesc& l = p->layers[i];
+      if (!l.is_conv && l.taps == 1 && l.cmap == CM_FLATTEN && l.cmap_a % PF_TC == 0 && l.cout % PF_TN == 0 &&
+          l.cin == l.cmap_a * l.cmap_b && l.w_off % 8 == 0 && l.wt_off % 8 == 0 && l.KP % 8 == 0 && l.KPt % 8 == 0 &&
+          p->img_total % 8 == 0 && p->imgt_total % 8 == 0 && l.cmap_a == 80 && l.cmap_b == 30)
+        flat_layer = i;
+    }
+  if (flat_layer >= 0) {
+    const LayerDesc& l = p->layers[flat_layer];
+    const SiteDesc& sd = p->ptab.site[l.site_w];
+    A.skip_lo = sd.off;
+    A.skip_hi = sd.off + sd.numel;
+    const int lds = 2 * PF_TN * PF_TC * l.cmap_b * 2;
+    const unsigned tiles = (unsigned)((l.cout / PF_TN) * (l.cmap_a / PF_TC));
+    const unsigned ny = (unsigned)(c->S + (c->mode == BNN_MODE_FLIPOUT ? 1 : 0));
+    const unsigned rest = (unsigned)((p->P - sd.numel + 255) / 256);
+    prep_fused_kernel<80, 30><<<dim3(tiles * ny + rest), dim3(256), lds, c->st>>>(A, flat_layer, l.site_w, tiles, ny);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  // 1024-thread workgroups: four times fewer fp64 atomics on the KL sum
+  const unsigned grid = (unsigned)((p->P + 1023) / 1024);
   if (p->d.prec == BNN_PREC_F32)
     prep_weights_kernel<PrecF32><<<dim3(grid), dim3(1024), 0, c->st>>>(A);
   else
