@@ -882,15 +882,18 @@ __global__ void predict_finish_kernel(const float* preds /*[S][B][2]*/, int B, i
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float s1 = 0.f, sv = 0.f;
+  const float2* pp = (const float2*)preds + b;   // (loc, scale) pairs; the sums keep the order s = 0, 1, ...
+#pragma unroll 10
   for (int s = 0; s < S; ++s) {
-    s1 += preds[((long)s * B + b) * 2];
-    const float sc = preds[((long)s * B + b) * 2 + 1];
-    sv += sc * sc;
+    const float2 v = pp[(long)s * B];
+    s1 += v.x;
+    sv += v.y * v.y;
   }
   const float mean = s1 / S;
   float ss = 0.f;
+#pragma unroll 10
   for (int s = 0; s < S; ++s) {
-    const float d = preds[((long)s * B + b) * 2] - mean;
+    const float d = pp[(long)s * B].x - mean;
     ss += d * d;
   }
   // unbiased variance (torch.var default); NaN at S == 1 like the reference

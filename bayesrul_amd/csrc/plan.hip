@@ -2318,7 +2318,8 @@ extern "C" int bnn_predict(BnnPlan* p, const float* x, int32_t batch, int32_t pa
     BNN_TRY(make_ctx(p, &a, &n2, stream, false, &c));
     c.s_base = s0;
     c.x_planes_ready = s0 > 0;   // same windows for every chunk of particles
-      BNN_TRY(prepare_noise(p, &a, &n2, &c));
+    BNN_TRY(prepare_noise(p, &a, &n2, &c));
+    if (s0 > 0) p->acc_clean = true;   // the KL / log-likelihood accumulators are not read on this path: no fill per chunk
     BNN_TRY(do_sample(p, &a, &c));
     BNN_TRY(do_forward(p, &a, &c, x));
     BNN_TRY(do_head(p, &a, &c, preds_all + (long)s0 * batch * 2, false));
