@@ -1,6 +1,7 @@
 #!/bin/bash
 # Diagnostics (not part of the product): builds variants of the library with parts of the fused trunk kernels removed
-# (-DTR_ABL / -DTX_ABL / -DDK_ABL bit masks, results wrong) and times the step with each.  Run on the GPU box:
+# (-DTR_ABL / -DTX_ABL / -DDK_ABL bit masks, results wrong; -DTR_PERM=w0,...,w11 places the trunk forward roles on other
+# waves, results right) and times the step with each.  Run on the GPU box:
 #   bash tests/probes/ablate_gpu.sh "TR_ABL=1 TR_ABL=2 TX_ABL=1 ..."
 mkdir -p gpurun_out /tmp/abl
 cd bayesrul_amd/csrc
