@@ -362,6 +362,14 @@ __global__ __launch_bounds__(256) void head_last_kernel(const HeadLastArgs A) {
   const int s = blockIdx.y;
   const int B = A.H.B;
   __shared__ float dzs[4][HL_ROWS];
+  // the layer's two weight rows (W | dW: 4 x 128 B) once per workgroup: 32 dependent global loads per row thread otherwise
+  __shared__ uint4 wsh[4][8];
+  if (tid < 32) {
+    const int kk = tid >> 3, c8 = tid & 7;
+    const u16* src = (kk < 2 ? A.w_hi + A.stride_a * s : A.w_b + A.stride_b * s) + (long)(kk & 1) * A.KP + c8 * 8;
+    wsh[kk][c8] = (kk < 2 || FO) ? *(const uint4*)src : make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
   if (tid < HL_ROWS) {
     double ll = 0.0;
     float g0 = 0.f, g1 = 0.f;
@@ -377,8 +385,6 @@ __global__ __launch_bounds__(256) void head_last_kernel(const HeadLastArgs A) {
     dzs[2][tid] = h0;
     dzs[3][tid] = h1;
     if (idx < B) {
-      const u16* w = A.w_hi + A.stride_a * s;
-      const u16* wb = A.w_b + A.stride_b * s;
       uint32_t si[2] = {0u, 0u};
       if constexpr (FO) {
         si[0] = A.sg_in[r * A.siw];
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(256) void head_last_kernel(const HeadLastArgs A) {
       }
 #pragma unroll
       for (int c8 = 0; c8 < 8; ++c8) {
-        const uint4 w0 = *(const uint4*)(w + c8 * 8), w1 = *(const uint4*)(w + A.KP + c8 * 8);
+        const uint4 w0 = wsh[0][c8], w1 = wsh[1][c8];
         const f32x4 a0 = unpack_bf4(make_uint2(w0.x, w0.y)), a1 = unpack_bf4(make_uint2(w0.z, w0.w));
         const f32x4 b0 = unpack_bf4(make_uint2(w1.x, w1.y)), b1 = unpack_bf4(make_uint2(w1.z, w1.w));
         f32x4 d0, d1;
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) void head_last_kernel(const HeadLastArgs A) {
           d1[q] = g0 * a1[q] + g1 * b1[q];
         }
         if constexpr (FO) {
-          const uint4 v0 = *(const uint4*)(wb + c8 * 8), v1 = *(const uint4*)(wb + A.KP + c8 * 8);
+          const uint4 v0 = wsh[2][c8], v1 = wsh[3][c8];
           const f32x4 e0 = unpack_bf4(make_uint2(v0.x, v0.y)), e1 = unpack_bf4(make_uint2(v0.z, v0.w));
           const f32x4 f0 = unpack_bf4(make_uint2(v1.x, v1.y)), f1 = unpack_bf4(make_uint2(v1.z, v1.w));
           const uint32_t byte = (si[c8 >> 2] >> ((c8 & 3) * 8)) & 0xffu;
