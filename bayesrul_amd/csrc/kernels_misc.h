@@ -126,7 +126,7 @@ struct StepInputsArgs {
   unsigned b_x;
   unsigned b_sg[2 * BNN_MAX_LAYERS + 1];
 };
-__device__ __forceinline__ void x_planes4_dev(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F, long idx);
+__device__ __forceinline__ void x_planes4_dev8(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F, long idx8);
 
 __global__ __launch_bounds__(256) void step_inputs_kernel(const StepInputsArgs A) {
   const unsigned blk = blockIdx.x;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void step_inputs_kernel(const StepInputsArgs A
     return;
   }
   if (blk < A.b_sg[0]) {
-    x_planes4_dev(A.x, A.xp[0], A.xp[1], A.xp[2], A.xp[3], A.rows, A.L, A.F, (long)(blk - A.b_x) * 256 + threadIdx.x);
+    x_planes4_dev8(A.x, A.xp[0], A.xp[1], A.xp[2], A.xp[3], A.rows, A.L, A.F, (long)(blk - A.b_x) * 256 + threadIdx.x);
     return;
   }
   int e = 0;

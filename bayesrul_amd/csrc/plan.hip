@@ -665,7 +665,7 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
       nb += 1;
     }
     SI.b_x = nb;
-    nb += (unsigned)((SI.rows * 32 + 255) / 256);
+    nb += (unsigned)((SI.rows * 4 + 255) / 256);   // 8 channels per thread
     if (SG) SI.sg = *SG;
     for (int e = 0; e < SI.sg.n; ++e) {
       SI.b_sg[e] = nb;
