@@ -495,25 +495,7 @@ __global__ __launch_bounds__(TR_THREADS) void trunk_fwd_kernel(const TrunkArgs A
 
 // bf16 hi/lo planes [rows][32] of the raw fp32 windows and of their MaxPool1d(3,1,1) copy (block 1's pooled
 // branch, inception.py:41-46); channel pads zero.  rows = B * L, pooling stays inside a window.
-__device__ __forceinline__ void x_planes4_dev(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F, long idx) {
-  if (idx >= rows * 32) return;
-  const long r = idx >> 5;
-  const int c = (int)(idx & 31);
-  float v = 0.f, p = 0.f;
-  if (c < F) {
-    v = x[r * F + c];
-    p = v;
-    const int l = (int)(r % L);
-    if (l > 0) p = fmaxf(p, x[(r - 1) * F + c]);
-    if (l + 1 < L) p = fmaxf(p, x[(r + 1) * F + c]);
-  }
-  const u16 h = f2bf(v), ph = f2bf(p);
-  hi[idx] = h;
-  lo[idx] = f2bf(v - bf2f(h));
-  phi[idx] = ph;
-  plo[idx] = f2bf(p - bf2f(ph));
-}
-// the same for 8 channels per thread (one 16-byte store per plane): idx8 = row * 4 + channel group
+// 8 channels per thread (one 16-byte store per plane): idx8 = row * 4 + channel group
 __device__ __forceinline__ void x_planes4_dev8(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F, long idx8) {
   if (idx8 >= rows * 4) return;
   const long r = idx8 >> 2;
@@ -548,5 +530,5 @@ __device__ __forceinline__ void x_planes4_dev8(const float* x, u16* hi, u16* lo,
   *(uint4*)(plo + o) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
 }
 __global__ void x_planes4_kernel(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F) {
-  x_planes4_dev(x, hi, lo, phi, plo, rows, L, F, (long)blockIdx.x * blockDim.x + threadIdx.x);
+  x_planes4_dev8(x, hi, lo, phi, plo, rows, L, F, (long)blockIdx.x * blockDim.x + threadIdx.x);   // rows * 4 threads
 }

@@ -1624,7 +1624,7 @@ static int launch_trunk_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, cons
   const size_t plane = (size_t)p->d.max_batch * L * 32;
   u16* xp = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
   if (!g_dry && !c->x_planes_ready) {
-    x_planes4_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xp, xp + plane, xp + 2 * plane,
+    x_planes4_kernel<<<dim3((unsigned)((rows * 4 + 255) / 256)), dim3(256), 0, c->st>>>(x, xp, xp + plane, xp + 2 * plane,
                                                                                         xp + 3 * plane, rows, L, p->d.n_features);
     HIP_TRY(hipGetLastError());
   }
