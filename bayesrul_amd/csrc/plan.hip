@@ -23,6 +23,7 @@
 #include "kernels_trunk_dw.h"
 #include "kernels_dense_ks.h"
 #include "kernels_mlp.h"
+#include "kernels_f32.h"
 
 // ------------------------------------------------------------------------------------------
 // errors
@@ -398,6 +399,12 @@ static void layout_workspace(BnnPlan* p) {
   p->o_preds = take((size_t)S * p->d.max_batch * 2 * 4);
   p->o_poolgrad = take((size_t)cap * p->d.win_length * 128 * 4);
   p->o_amax = take(p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION ? (size_t)cap * p->d.win_length * 128 : 0);
+  if (p->d.prec == BNN_PREC_F32 && p->d.net == BNN_NET_INCEPTION) {
+    // fused fp32 trunk (kernels_f32.h): 2-bit arg-max codes and ReLU masks of ACT1 / MID, one byte per 4 channels
+    p->o_amax = take((size_t)cap * p->d.win_length * 32);
+    p->o_mact1 = take((size_t)cap * p->d.win_length * 32);
+    p->o_mmid = take((size_t)cap * p->d.win_length * 32);
+  }
   // fused trunk dW: one partial image per workgroup, S * nsplit <= 256 (512 for the k3 / k5 kernel) whatever the call
   p->slab_stride = 0;
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
@@ -1789,9 +1796,79 @@ static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, bool 
   return 0;
 }
 
+// fused fp32 conv trunk (kernels_f32.h): groups 0..2 of the Inception net in one launch, exact fp32 MFMA
+static bool tf_ok(const BnnPlan* p, const Ctx* c) {
+  return p->d.prec == BNN_PREC_F32 && p->d.net == BNN_NET_INCEPTION && c->em != EM_LRT && p->d.win_length <= 30 &&
+         p->d.n_features == 18;
+}
+
+static int tf_check_tables(const BnnPlan* p) {
+  for (int l = 0; l < 10; ++l) {
+    const LayerDesc& ly = p->layers[l];
+    if (ly.cin_img != tf_cimg(l) || ly.taps != tl_taps(l) || ly.cout != tl_cout(l) || ly.KP != rup(ly.taps * ly.cin_img, 32) ||
+        (ly.w_off & 3) || (ly.wt_off & 3) || (ly.KPt & 3))
+      return fail(BNN_E_INVALID, "fp32 trunk kernels: layer %d does not match the compiled geometry", l);
+  }
+  if ((p->img_total & 3) || (p->imgt_total & 3)) return fail(BNN_E_INVALID, "fp32 trunk kernels: image strides");
+  return 0;
+}
+
+static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
+  const int L = p->d.win_length;
+  const long rows = (long)c->B * L;
+  float* xp = (float*)((char*)p->bufs.workspace + p->o_xplanes);
+  const size_t plane = (size_t)p->d.max_batch * L * TF_XC;
+  BNN_TRY(tf_check_tables(p));
+  if (!g_dry && !c->x_planes_ready) {
+    xf_planes_kernel<<<dim3((unsigned)((rows * 5 + 255) / 256)), dim3(256), 0, c->st>>>(x, xp, xp + plane, rows, L, p->d.n_features);
+    HIP_TRY(hipGetLastError());
+  }
+  GroupArgs G;
+  fill_group_args(p, a, c, 0, x, &G);
+  TfArgs T{};
+  T.xp[0] = xp;
+  T.xp[1] = xp + plane;
+  T.ws = G.ws;
+  T.layers = G.layers;
+  T.sign_in = c->nz.sign_in;
+  T.sign_out = c->nz.sign_out;
+  T.examples = (long)c->S * c->B;
+  T.act1 = c->train ? tens_ptr(p, TI_ACT1, 0) : nullptr;
+  T.mid = c->train ? tens_ptr(p, TI_MID, 0) : nullptr;
+  T.act2 = tens_ptr(p, TI_ACT2, 0);
+  T.amax = c->train ? (unsigned char*)p->bufs.workspace + p->o_amax : nullptr;
+  T.m_act1 = c->train ? (unsigned char*)p->bufs.workspace + p->o_mact1 : nullptr;
+  T.m_mid = c->train ? (unsigned char*)p->bufs.workspace + p->o_mmid : nullptr;
+  T.S = c->S;
+  T.B = c->B;
+  T.L = L;
+  T.nsplit = std::max(1, std::min(c->B, 256 / std::max(1, c->S)));
+  static_assert(TF_LDS <= 160 * 1024, "LDS budget");
+  if ((long)c->S * c->B * L * 512 >= (1L << 32))
+    return fail(BNN_E_INVALID, "fp32 trunk kernels address rows with 32-bit byte offsets: S*B*L = %ld rows exceed 2^23", (long)c->S * c->B * L);
+  const unsigned grid = (unsigned)(c->S * T.nsplit);
+  ProfScope ps_(&p->prof, PK_FWD, 0, c->st);
+  ps_.name("tf_fwd_kernel<%d, %s>", c->em, c->train ? "true" : "false");
+#define LAUNCH_TF(EMV, TRV)                                                               \
+  do {                                                                                    \
+    BNN_TRY(set_lds(tf_fwd_kernel<EMV, TRV>, TF_LDS));                                    \
+    tf_fwd_kernel<EMV, TRV><<<dim3(grid), dim3(TF_THREADS), TF_LDS, c->st>>>(T);          \
+  } while (0)
+  BNN_DRY_RETURN();
+  if (c->em == EM_FLIPOUT) {
+    if (c->train) LAUNCH_TF(EM_FLIPOUT, true); else LAUNCH_TF(EM_FLIPOUT, false);
+  } else {
+    if (c->train) LAUNCH_TF(EM_PLAIN, true); else LAUNCH_TF(EM_PLAIN, false);
+  }
+#undef LAUNCH_TF
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
-  const bool trunk = trunk_ok(p, c);
+  const bool tf = tf_ok(p, c);
+  const bool trunk = trunk_ok(p, c) || tf;
   p->fwd_fused_last = false;
   if (mlp_ok(p, c)) {
     BNN_TRY(launch_mlp_fwd(p, a, c, x));
@@ -1799,7 +1876,8 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
     p->last_B = c->B;
     return 0;
   }
-  if (trunk) BNN_TRY(launch_trunk_fwd(p, a, c, x));
+  if (tf) BNN_TRY(launch_tf_fwd(p, a, c, x));
+  else if (trunk) BNN_TRY(launch_trunk_fwd(p, a, c, x));
   if (bf && p->d.net == BNN_NET_INCEPTION && !trunk) {
     const long rows = (long)c->B * p->d.win_length;
     u16* xh = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
