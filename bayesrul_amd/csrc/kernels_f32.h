@@ -425,7 +425,7 @@ __global__ void xf_planes_kernel(const float* x, float* xp, float* xpp, long row
 //   Weights: transposed + tap-flipped images, register-stationary.  Flipout: BOTH sign vectors are folded into the dW^T
 //   fragment (row = input channel -> s_in bit, K = cout -> s_out nibble; the forward's table), so both contractions
 //   share the dz operand and the accumulator.  Wave w owns tile w of stage B (176 MFMAs per window with Flipout) and one
-//   tile of stage A (layer 6: 48, waves 0..3; layer 8: 80, waves 4..7): every SIMD carries 480.  Waves 0 and 1 also stage
+//   tile of stage A (layer 6: 48, waves 0..3; layer 8: 80, waves 4..7): every SIMD carries 480.  Waves 0..3 also stage
 //   the next window's dY(ACT2) (global -> registers, one step ahead -> LDS), masking it with [ACT2 > 0] unless PRE.
 // ==========================================================================================
 enum {
@@ -575,8 +575,6 @@ struct TdJobB {
     const char* bm = dzm + (i16 + HALO) * TF_RSB + g4 * 16;
 #pragma unroll
     for (int q = 0; q < 11; ++q) {
-      constexpr int dummy = 0;
-      (void)dummy;
       f32x4 x[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -643,12 +641,12 @@ struct TdJobB {
   }
 };
 
-// dY(ACT2) of the next windows (and the Flipout sign words): loader wave p of 2 takes the chunks (2 j + p) * 64 + lane
+// dY(ACT2) of the next windows (and the Flipout sign words): loader wave p of 4 takes the chunks (4 j + p) * 64 + lane
 template <bool FO, bool PRE>
 struct TdLoader {
-  int qo[5], dst[5];
-  bool on[5];
-  tf_u32x4 g[5], y[PRE ? 1 : 5];
+  int qo[3], dst[3];
+  bool on[3];
+  tf_u32x4 g[3], y[PRE ? 1 : 3];
   const uint32_t* sg0 = nullptr;
   const uint32_t* sg1 = nullptr;
   long sst0 = 0, sst1 = 0;
@@ -661,8 +659,8 @@ struct TdLoader {
     Rs = ((long)s * A.B + split) * A.L;
     Rstep = (long)A.nsplit * A.L;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int q = (2 * j + p) * 64 + lane;
+    for (int j = 0; j < 3; ++j) {
+      const int q = (4 * j + p) * 64 + lane;
       on[j] = q < n2;
       const int qq = on[j] ? q : 0;
       qo[j] = qq * 16;
@@ -688,11 +686,11 @@ struct TdLoader {
   __device__ __forceinline__ void fetch(const TfDxArgs& A, int k) {
     const char* gp = (const char*)A.g_act2 + (Rs + k * Rstep) * 320;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) g[j] = *(const tf_u32x4*)(gp + qo[j]);
+    for (int j = 0; j < 3; ++j) g[j] = *(const tf_u32x4*)(gp + qo[j]);
     if constexpr (!PRE) {
       const char* yp = (const char*)A.act2 + (Rs + k * Rstep) * 320;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) y[j] = *(const tf_u32x4*)(yp + qo[j]);
+      for (int j = 0; j < 3; ++j) y[j] = *(const tf_u32x4*)(yp + qo[j]);
     }
     if constexpr (FO) {
       if (sg0) sb0 = sg0[(long)k * sst0];
@@ -703,7 +701,7 @@ struct TdLoader {
     char* sl = smem + TD_O_DZ2 + (k % 3) * TD_P2;
     char* gd = (char*)A.g_act2m + (Rs + k * Rstep) * 320;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < 3; ++j) {
       if (on[j]) {
         tf_u32x4 d = g[j];
         if constexpr (!PRE) {
@@ -732,7 +730,7 @@ __device__ __forceinline__ void td_role(const TfDxArgs& A, char* smem, int s, in
   TdJobA<EM, (W < 4 ? 6 : 8), (W & 3)> ja;
   jb.init(A, s, lane);
   ja.init(A, s, lane);
-  constexpr bool LOADER = W < 2;
+  constexpr bool LOADER = W < 4;
   TdLoader<FO, PRE> ld;
   if constexpr (LOADER) {
     ld.setup(A, s, split, lane, W);
@@ -778,5 +776,771 @@ __global__ __launch_bounds__(TF_THREADS) void tf_dx_kernel(const TfDxArgs A) {
     case 5: td_role<EM, PRE, 5>(A, smem, s, split, nwin, lane); break;
     case 6: td_role<EM, PRE, 6>(A, smem, s, split, nwin, lane); break;
     default: td_role<EM, PRE, 7>(A, smem, s, split, nwin, lane); break;
+  }
+}
+
+// ==========================================================================================
+// tf_dw_kernel<EM, KIND> : weight gradients of the conv trunk (exact fp32), two launches:
+//   KIND 0 : block 1 (layers 0-3: x / pooled x, dz(ACT1)) and the k3 / k5 level (layers 6, 8: MID, dz(ACT2) 16..47)
+//   KIND 1 : the 1x1 level (layers 4, 5, 7 and the pooled layer 9: ACT1, dz(MID), dz(ACT2) 0..15 / 48..79)
+// dW[n][tap][c] += sum_rows dz[row][n] * X[row + tap - pad][c]: the contraction index is the window row; both operands
+// are COLUMN reads of [row][channel] LDS images (ds_read_b32; row pitches of 16 (mod 32) words put the 4 rows of a k-step
+// on disjoint bank groups).  Tiles are accumulated transposed (rows = input channels, columns = couts) and stay in
+// registers across the workgroup's windows; they are written once into the workgroup's partial image ("slab", forward
+// image layout), summed by slab_reduce_kernel in a fixed order.
+// Flipout: the signs of a conv layer are per (window, channel), constant over the rows of a window, so the second
+// product is  (dz o s_out)^T (x o s_in) = (s_in (x) s_out) o (dz^T x):  ONE contraction T per tile and window,
+// acc_mean += T, acc_dW += signs o T (8 VALU instructions instead of 8 MFMAs).
+// Layer 9's operand MaxPool1d(3,1,1)(ACT1) is the maximum of three row-shifted reads of the ACT1 image (ACT1 >= 0, the
+// zero halo rows are the pool's identity).  All 8 waves stage a share of the next window (registers, one step ahead).
+// ==========================================================================================
+enum {
+  TFW_RX = 192, TFW_RB = 576, TFW_RZA = 192, TFW_RZB = 320,
+  TFW0_O_X = 0, TFW0_O_XP = TFW0_O_X + IMG_ROWS * TFW_RX, TFW0_O_DZ1 = TFW0_O_XP + IMG_ROWS * TFW_RX,
+  TFW0_O_MID = TFW0_O_DZ1 + TILE_ROWS * TFW_RB, TFW0_O_DZ2 = TFW0_O_MID + IMG_ROWS * TFW_RB, TFW0_SLOT = TFW0_O_DZ2 + TILE_ROWS * TFW_RZA,
+  TFW1_O_A1 = 0, TFW1_O_DZM = TFW1_O_A1 + IMG_ROWS * TFW_RB, TFW1_O_DZ2 = TFW1_O_DZM + TILE_ROWS * TFW_RB, TFW1_SLOT = TFW1_O_DZ2 + TILE_ROWS * TFW_RZB,
+  TFW_NLD = 5   // 16-byte chunks per thread and window
+};
+template <int KIND> __host__ __device__ constexpr int tw_slot() { return KIND == 0 ? TFW0_SLOT : TFW1_SLOT; }
+template <int KIND> __host__ __device__ constexpr int tw_lds() { return 2 * tw_slot<KIND>() + 2 * 80 * 4; }
+
+struct TfDwArgs {
+  const float* xp[2];      // [B*L][20] x, pooled x
+  const float* act1;       // [S*B*L][128]
+  const float* mid;        // [S*B*L][128]
+  const float* g_act1;     // dz (masked) of ACT1 / MID / ACT2
+  const float* g_mid;
+  const float* g_act2;     // [S*B*L][80]
+  const LayerDesc* layers;
+  const uint32_t* sign_in;
+  const uint32_t* sign_out;
+  long examples;
+  float* gw_a; float* gw_b; float* gb_a;   // slabs: [S * nsplit][gw_stride] / [S * nsplit][gb_stride]
+  long gw_stride; int gb_stride;
+  int S, B, L, nsplit;
+};
+
+// image geometry of a layer's operands inside a slot
+template <int KIND> __host__ __device__ constexpr int tw_zoff(int l) { return KIND == 0 ? (l < 4 ? TFW0_O_DZ1 : TFW0_O_DZ2) : ((l == 5 || l == 7) ? TFW1_O_DZM : TFW1_O_DZ2); }
+template <int KIND> __host__ __device__ constexpr int tw_zpitch(int l) { return KIND == 0 ? (l < 4 ? TFW_RB : TFW_RZA) : ((l == 5 || l == 7) ? TFW_RB : TFW_RZB); }
+template <int KIND> __host__ __device__ constexpr int tw_zch(int l) { return KIND == 0 ? (l < 4 ? l * 32 : (l == 6 ? 0 : 16)) : (l == 7 ? 64 : (l == 9 ? 48 : 0)); }
+template <int KIND> __host__ __device__ constexpr int tw_xoff(int l) { return KIND == 0 ? (l < 3 ? TFW0_O_X : (l == 3 ? TFW0_O_XP : TFW0_O_MID)) : TFW1_O_A1; }
+template <int KIND> __host__ __device__ constexpr int tw_xpitch(int l) { return KIND == 0 ? (l < 4 ? TFW_RX : TFW_RB) : TFW_RB; }
+__host__ __device__ constexpr int tw_xch(int l) { return l == 8 ? 64 : 0; }
+
+// one (layer, n-tile) job over the c-tiles [CT0, CT0 + NCT) of the layer's own input channels, all taps
+template <int EM, int KIND, int LY, int NT, int CT0, int NCT, bool BIAS>
+struct TwJob {
+  static constexpr bool FO = (EM == EM_FLIPOUT);
+  static constexpr int TAPS = tl_taps(LY), PAD = (TAPS - 1) / 2, NTILE = TAPS * NCT;
+  static constexpr bool POOL3 = (KIND == 1 && LY == 9);
+  f32x4 acc_a[NTILE], acc_b[FO ? NTILE : 1];
+  float bsum;
+
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      acc_a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FO) acc_b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    bsum = 0.f;
+  }
+
+  __device__ __forceinline__ void load_a(const char* sl, int tt, int lane, float (&ax)[8]) const {
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int tap = tt / NCT, c = tt - tap * NCT;
+    const char* xi = sl + tw_xoff<KIND>(LY) + (tw_xch(LY) + (CT0 + c) * 16 + i16) * 4 + (g4 + tap - PAD + HALO) * tw_xpitch<KIND>(LY);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const char* q = xi + 4 * ks * tw_xpitch<KIND>(LY);
+      if constexpr (POOL3) ax[ks] = fmaxf(fmaxf(*(const float*)(q - TFW_RB), *(const float*)q), *(const float*)(q + TFW_RB));
+      else ax[ks] = *(const float*)q;
+    }
+  }
+
+  __device__ __forceinline__ void fold(int tt, f32x4 T, const uint32_t* sg, uint32_t sob, int lane) {
+    acc_a[tt] += T;
+    if constexpr (FO) {
+      const int g4 = lane >> 4;
+      const int c = tt % NCT;
+      const int cbit = (CT0 + c) * 16;   // the layer's own input channel of row 0 of the tile
+      const uint32_t nib = (sg[LY * 8 + (cbit >> 5)] >> ((cbit & 31) + 4 * g4)) & 15u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_b[tt][r] += xor1(T[r], (((nib >> r) & 1u) ^ sob) << 31);
+    }
+  }
+
+  __device__ __forceinline__ void run(const char* sl, const uint32_t* sg, int lane) {
+    __builtin_amdgcn_sched_barrier(0);
+    const int i16 = lane & 15, g4 = lane >> 4;
+    constexpr int n0 = tw_zch<KIND>(LY) + NT * 16;
+    const char* zi = sl + tw_zoff<KIND>(LY) + g4 * tw_zpitch<KIND>(LY) + (n0 + i16) * 4;
+    float bz[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) bz[ks] = *(const float*)(zi + 4 * ks * tw_zpitch<KIND>(LY));
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) bsum += bz[ks];
+    }
+    uint32_t sob = 0;
+    if constexpr (FO) sob = (sg[LY * 8 + 4 + ((NT * 16) >> 5)] >> (((NT * 16) & 31) + i16)) & 1u;   // s_out of this lane's column (cout)
+#pragma unroll
+    for (int tt = 0; tt < NTILE; tt += 2) {
+      // two tiles at a time: their MFMA chains interleave (a dependent 16x16x4 pair is 40 cycles apart, an issue slot 32)
+      float ax0[8], ax1[8];
+      load_a(sl, tt, lane, ax0);
+      if (tt + 1 < NTILE) load_a(sl, tt + 1, lane, ax1);
+      f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        T0 = mfma4(ax0[ks], bz[ks], T0);
+        if (tt + 1 < NTILE) T1 = mfma4(ax1[ks], bz[ks], T1);
+      }
+      fold(tt, T0, sg, sob, lane);
+      if (tt + 1 < NTILE) fold(tt + 1, T1, sg, sob, lane);
+    }
+  }
+
+  __device__ __forceinline__ void flush(const TfDwArgs& A, int slab, int lane) const {
+    const LayerDesc ly = A.layers[LY];
+    const int g4 = lane >> 4, n = NT * 16 + (lane & 15);
+    float* gwa = A.gw_a + A.gw_stride * slab + ly.w_off;
+    float* gwb = A.gw_b + A.gw_stride * slab + ly.w_off;
+    if (n < ly.cout) {
+#pragma unroll
+      for (int tt = 0; tt < NTILE; ++tt) {
+        const int tap = tt / NCT, c = tt - tap * NCT;
+        // transposed tile: this lane holds the image channels ch .. ch+3 of cout n (channel pads are zero columns)
+        const long o = (long)n * ly.KP + (long)tap * ly.cin_img + (CT0 + c) * 16 + 4 * g4;
+        *(f32x4*)(gwa + o) = acc_a[tt];
+        if constexpr (FO) *(f32x4*)(gwb + o) = acc_b[tt];
+      }
+    }
+    if constexpr (BIAS) {
+      float t = bsum;   // lane group g4 summed the rows g4 (mod 4)
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (g4 == 0 && n < ly.cout) A.gb_a[(long)A.gb_stride * slab + ly.bias_off + n] = t;
+    }
+  }
+};
+
+struct TwNone {
+  __device__ __forceinline__ void init() {}
+  __device__ __forceinline__ void run(const char*, const uint32_t*, int) {}
+  __device__ __forceinline__ void flush(const TfDwArgs&, int, int) const {}
+};
+
+// every thread stages TFW_NLD 16-byte chunks of each window: the streams of a kind are enumerated back to back
+struct TwStream {
+  const char* base;   // first row of window 0 of this workgroup (+ first byte of the column range)
+  int rowbytes;       // global row stride
+  int cpr;            // chunks per row
+  int dstoff, dpitch; // inside a slot
+};
+template <bool FO>
+struct TwLoader {
+  const char* src[TFW_NLD];
+  int wstep[TFW_NLD], dst[TFW_NLD];
+  bool on[TFW_NLD];
+  tf_u32x4 d[TFW_NLD];
+  const uint32_t* sg0 = nullptr;
+  const uint32_t* sg1 = nullptr;
+  long sst0 = 0, sst1 = 0;
+  uint32_t sb0 = 0, sb1 = 0;
+  __device__ __forceinline__ void setup(const TfDwArgs& A, const TwStream* st, int nst, int s, int split, int tid) {
+    const int L = A.L;
+#pragma unroll
+    for (int j = 0; j < TFW_NLD; ++j) {
+      int q = j * TF_THREADS + tid;
+      on[j] = false;
+      src[j] = st[0].base;
+      wstep[j] = 0;
+      dst[j] = 0;
+      for (int i = 0; i < nst; ++i) {
+        const int n = L * st[i].cpr;
+        if (q >= 0 && q < n) {
+          const int row = q / st[i].cpr, c = q - row * st[i].cpr;
+          on[j] = true;
+          src[j] = st[i].base + (long)row * st[i].rowbytes + c * 16;
+          wstep[j] = A.nsplit * L * st[i].rowbytes;
+          dst[j] = st[i].dstoff + row * st[i].dpitch + c * 16;
+        }
+        q -= n;
+      }
+    }
+    if constexpr (FO) {
+      if (tid < 64) {
+        const int lane = tid;
+        auto one = [&](int layer, int kk, const uint32_t*& q, long& stride) {
+          const LayerDesc ly = A.layers[layer];
+          if (kk < 4 && kk < ly.sign_in_words) {
+            q = A.sign_in + ly.sign_in_off * A.examples + ((long)s * A.B + split) * ly.sign_in_words + kk;
+            stride = (long)A.nsplit * ly.sign_in_words;
+          } else if (kk >= 4 && kk - 4 < ly.sign_out_words && kk < 6) {
+            q = A.sign_out + ly.sign_out_off * A.examples + ((long)s * A.B + split) * ly.sign_out_words + (kk - 4);
+            stride = (long)A.nsplit * ly.sign_out_words;
+          }
+        };
+        one(lane >> 3, lane & 7, sg0, sst0);
+        if (lane < 16) one(8 + (lane >> 3), lane & 7, sg1, sst1);
+      }
+    }
+  }
+  __device__ __forceinline__ void fetch(int k) {
+#pragma unroll
+    for (int j = 0; j < TFW_NLD; ++j) d[j] = *(const tf_u32x4*)(src[j] + (long)k * wstep[j]);
+    if constexpr (FO) {
+      if (sg0) sb0 = sg0[(long)k * sst0];
+      if (sg1) sb1 = sg1[(long)k * sst1];
+    }
+  }
+  __device__ __forceinline__ void put(char* slot, uint32_t* sgw, int tid) {
+#pragma unroll
+    for (int j = 0; j < TFW_NLD; ++j)
+      if (on[j]) *(tf_u32x4*)(slot + dst[j]) = d[j];
+    if constexpr (FO) {
+      if (tid < 64) {
+        sgw[tid] = sb0;
+        if (tid < 16) sgw[64 + tid] = sb1;
+      }
+    }
+  }
+};
+
+template <int EM, int KIND, class J0, class J1, class J2>
+__device__ __forceinline__ void tw_role(const TfDwArgs& A, char* smem, const TwStream* st, int nst, int s, int split, int nwin, int tid) {
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  constexpr int SLOT = tw_slot<KIND>();
+  const int lane = tid & 63;
+  J0 j0;
+  J1 j1;
+  J2 j2;
+  j0.init();
+  j1.init();
+  j2.init();
+  TwLoader<FO> ld;
+  ld.setup(A, st, nst, s, split, tid);
+  uint32_t* sgb = (uint32_t*)(smem + 2 * SLOT);
+  if (nwin > 0) ld.fetch(0);
+  __syncthreads();   // zero fill
+  if (nwin > 0) ld.put(smem, sgb, tid);
+  if (nwin > 1) ld.fetch(1);
+  lds_barrier();
+  for (int t = 0; t < nwin; ++t) {
+    if (t + 1 < nwin) ld.put(smem + ((t + 1) & 1) * SLOT, sgb + ((t + 1) & 1) * 80, tid);
+    if (t + 2 < nwin) ld.fetch(t + 2);
+    const char* sl = smem + (t & 1) * SLOT;
+    const uint32_t* sg = sgb + (t & 1) * 80;
+    j0.run(sl, sg, lane);
+    j1.run(sl, sg, lane);
+    j2.run(sl, sg, lane);
+    lds_barrier();
+  }
+  j0.flush(A, (int)blockIdx.x, lane);   // slab = this workgroup's (particle, split)
+  j1.flush(A, (int)blockIdx.x, lane);
+  j2.flush(A, (int)blockIdx.x, lane);
+}
+
+template <int EM, int KIND>
+__global__ __launch_bounds__(TF_THREADS) void tf_dw_kernel(const TfDwArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x / A.nsplit, split = blockIdx.x - s * A.nsplit;
+  const int nwin = (A.B - split + A.nsplit - 1) / A.nsplit;
+  const int L = A.L;
+  {
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < tw_lds<KIND>() / 4; k += TF_THREADS) z[k] = 0u;
+  }
+  const long pr = ((long)s * A.B + split) * L;   // first row of this workgroup's window 0 in the [S*B*L] row space
+  TwStream st[5];
+  int nst;
+  if constexpr (KIND == 0) {
+    st[0] = TwStream{(const char*)A.xp[0] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFW0_O_X + HALO * TFW_RX, TFW_RX};
+    st[1] = TwStream{(const char*)A.xp[1] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFW0_O_XP + HALO * TFW_RX, TFW_RX};
+    st[2] = TwStream{(const char*)A.g_act1 + pr * 512, 512, 32, TFW0_O_DZ1, TFW_RB};
+    st[3] = TwStream{(const char*)A.mid + pr * 512, 512, 32, TFW0_O_MID + HALO * TFW_RB, TFW_RB};
+    st[4] = TwStream{(const char*)A.g_act2 + pr * 320 + 64, 320, 8, TFW0_O_DZ2, TFW_RZA};
+    nst = 5;
+  } else {
+    st[0] = TwStream{(const char*)A.act1 + pr * 512, 512, 32, TFW1_O_A1 + HALO * TFW_RB, TFW_RB};
+    st[1] = TwStream{(const char*)A.g_mid + pr * 512, 512, 32, TFW1_O_DZM, TFW_RB};
+    st[2] = TwStream{(const char*)A.g_act2 + pr * 320, 320, 20, TFW1_O_DZ2, TFW_RZB};
+    nst = 3;
+  }
+#define TWJ(...) TwJob<EM, KIND, __VA_ARGS__>
+#define TW_ROLE(...) tw_role<EM, KIND, __VA_ARGS__>(A, smem, st, nst, s, split, nwin, tid)
+  if constexpr (KIND == 0) {
+    // tiles per wave: 10 10 10 10 9 11 11 9 (8 MFMAs each per window); wave w and w + 4 share SIMD w
+    switch (wave) {
+      case 0: TW_ROLE(TWJ(2, 0, 0, 2, true), TwNone, TwNone); break;
+      case 1: TW_ROLE(TWJ(2, 1, 0, 2, true), TwNone, TwNone); break;
+      case 2: TW_ROLE(TWJ(8, 0, 0, 2, true), TwNone, TwNone); break;
+      case 3: TW_ROLE(TWJ(8, 0, 2, 2, false), TwNone, TwNone); break;
+      case 4: TW_ROLE(TWJ(1, 0, 0, 2, true), TWJ(6, 0, 3, 1, false), TwNone); break;
+      case 5: TW_ROLE(TWJ(1, 1, 0, 2, true), TWJ(6, 0, 0, 1, true), TWJ(0, 0, 0, 2, true)); break;
+      case 6: TW_ROLE(TWJ(3, 0, 0, 2, true), TWJ(6, 0, 1, 1, false), TWJ(0, 1, 0, 2, true)); break;
+      default: TW_ROLE(TWJ(3, 1, 0, 2, true), TWJ(6, 0, 2, 1, false), TwNone); break;
+    }
+  } else {
+    // 11 tiles per wave
+    switch (wave) {
+      case 0: TW_ROLE(TWJ(5, 0, 0, 8, true), TWJ(4, 0, 0, 3, true), TwNone); break;
+      case 1: TW_ROLE(TWJ(5, 1, 0, 8, true), TWJ(4, 0, 3, 3, false), TwNone); break;
+      case 2: TW_ROLE(TWJ(5, 2, 0, 8, true), TWJ(4, 0, 6, 2, false), TWJ(9, 0, 0, 1, true)); break;
+      case 3: TW_ROLE(TWJ(5, 3, 0, 8, true), TWJ(9, 0, 1, 3, false), TwNone); break;
+      case 4: TW_ROLE(TWJ(7, 0, 0, 8, true), TWJ(9, 0, 4, 3, false), TwNone); break;
+      case 5: TW_ROLE(TWJ(7, 1, 0, 8, true), TWJ(9, 0, 7, 1, false), TWJ(9, 1, 0, 2, true)); break;
+      case 6: TW_ROLE(TWJ(7, 2, 0, 8, true), TWJ(9, 1, 2, 3, false), TwNone); break;
+      default: TW_ROLE(TWJ(7, 3, 0, 8, true), TWJ(9, 1, 5, 3, false), TwNone); break;
+    }
+  }
+#undef TW_ROLE
+#undef TWJ
+}
+
+// ==========================================================================================
+// Flatten -> Linear(80 L, 64) of the Inception net (inception.py:200-216) in exact fp32: K-split, weight-stationary.
+//   workgroup = (particle, 240-channel K chunk, row range); the chunk's weight fragments (mean | per-particle W, Flipout
+//   dW) live in registers for the whole launch, the example rows stream through LDS in 32-row steps (all waves stage a
+//   share: registers, one step ahead).  Flipout's signs are per EXAMPLE here, i.e. per row: s_in is folded into the
+//   activation fragment (sign words of the step's rows in LDS), s_out is applied to the perturbation accumulator in the
+//   epilogue.  densef_fwd writes per-chunk partial pre-activations; dense_ks_fin_kernel sums them in order (+ bias, ReLU).
+// ==========================================================================================
+enum {
+  FDF_CH = 240, FDF_KB = FDF_CH / 16, FDF_ROWS = 32,
+  FDF_RSX = FDF_CH * 4 + 32,                   // 992 bytes: pitch 62 (row reads of the forward)
+  FDF_SGW = 12,                               // sign words per row: 9 s_in words covering the chunk + 2 s_out + pad
+  FDF_O_SG = FDF_ROWS * FDF_RSX,
+  FDF_SLOT = FDF_O_SG + FDF_ROWS * FDF_SGW * 4,  // 33,280
+  FDF_NSLOT = 3,
+  FDF_O_LUT = FDF_NSLOT * FDF_SLOT,
+  FDF_LDS = FDF_O_LUT + 32 * 16
+};
+
+struct DfArgs {
+  const float* x;                     // [S*B][x_ctot] fp32: the layer's input rows
+  int x_ctot;
+  const float* wa; const float* wb;   // forward images of the layer [64][KP] (slot A: mean | sampled W, slot B: dW), offset to the layer
+  long stride_a, stride_b;            // elements between particles (0: shared)
+  int KP;
+  const uint32_t* sg_in; const uint32_t* sg_out;   // packed signs of the layer [S*B][siw] / [S*B][sow]
+  int siw, sow;
+  float* slab;                        // [nchunk][S*B][64] partial pre-activations
+  long slab_stride;
+  int S, B, nchunk, nrs, rows_per_wg;
+};
+
+template <int EM>
+__global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = wave & 3, mh = wave >> 2;
+  int bid = blockIdx.x;
+  const int rs = bid % A.nrs;
+  bid /= A.nrs;
+  const int chunk = bid % A.nchunk, s = bid / A.nchunk;
+  if (s >= A.S) return;
+  const int b0 = rs * A.rows_per_wg, b1 = min(A.B, b0 + A.rows_per_wg);
+  const int nsteps = (b1 - b0 + FDF_ROWS - 1) / FDF_ROWS;
+  const int ch0 = chunk * FDF_CH;
+  const int w0 = ch0 >> 5;   // first s_in word of the chunk
+  build_sign_lut_f32((uint4*)(smem + FDF_O_LUT), tid);
+  // ---- weight fragments: rows nt*16 + i16 of the forward image, k-blocks of the chunk ----
+  f32x4 wa[FDF_KB], wb[FO ? FDF_KB : 1];
+  {
+    const float* pa = A.wa + A.stride_a * s + (long)(nt * 16 + i16) * A.KP + ch0 + 4 * g4;
+    const float* pb = A.wb + A.stride_b * s + (long)(nt * 16 + i16) * A.KP + ch0 + 4 * g4;
+#pragma unroll
+    for (int kb = 0; kb < FDF_KB; ++kb) {
+      wa[kb] = *(const f32x4*)(pa + kb * 16);
+      if constexpr (FO) wb[kb] = *(const f32x4*)(pb + kb * 16);
+    }
+  }
+  // ---- staging plan: 4 chunks of the step's [32][240] rows per thread, sign words by the first 352 threads ----
+  int xq_row[4], xq_off[4], xq_dst[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = j * TF_THREADS + tid;   // < 2048; rows 0..31 x 60 chunks = 1920
+    const int row = min(q / 60, FDF_ROWS - 1), c = q % 60;
+    xq_row[j] = q < FDF_ROWS * 60 ? row : -1;
+    xq_off[j] = ch0 * 4 + c * 16;
+    xq_dst[j] = row * FDF_RSX + c * 16;
+  }
+  const int sq_row = tid / 11, sq_w = tid - sq_row * 11;
+  const bool sq_on = FO && tid < FDF_ROWS * 11;
+  tf_u32x4 xr[4];
+  uint32_t sw = 0;
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const int bb = b0 + t * FDF_ROWS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long R = (long)s * A.B + min(bb + max(xq_row[j], 0), A.B - 1);
+      xr[j] = *(const tf_u32x4*)((const char*)A.x + R * A.x_ctot * 4 + xq_off[j]);
+    }
+    if constexpr (FO) {
+      if (sq_on) {
+        const long R = (long)s * A.B + min(bb + sq_row, A.B - 1);
+        sw = sq_w < 9 ? A.sg_in[R * A.siw + min(w0 + sq_w, A.siw - 1)] : A.sg_out[R * A.sow + min(sq_w - 9, A.sow - 1)];
+      }
+    }
+  };
+  auto put = [&](int t) __attribute__((always_inline)) {
+    char* sl = smem + (t % FDF_NSLOT) * FDF_SLOT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (xq_row[j] >= 0) *(tf_u32x4*)(sl + xq_dst[j]) = xr[j];
+    if constexpr (FO) {
+      if (sq_on) ((uint32_t*)(sl + FDF_O_SG))[sq_row * FDF_SGW + sq_w] = sw;
+    }
+  };
+  if (nsteps > 0) fetch(0);
+  __syncthreads();   // LUT
+  if (nsteps > 0) put(0);
+  if (nsteps > 1) fetch(1);
+  lds_barrier();
+  const uint4* lut = (const uint4*)(smem + FDF_O_LUT);
+  for (int t = 0; t < nsteps; ++t) {
+    const char* sl = smem + (t % FDF_NSLOT) * FDF_SLOT;
+    const uint32_t* sgl = (const uint32_t*)(sl + FDF_O_SG) + (mh * 16 + i16) * FDF_SGW;
+    const char* lb = sl + (mh * 16 + i16) * FDF_RSX + g4 * 16;
+    f32x4 accm = {0.f, 0.f, 0.f, 0.f}, accp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < FDF_KB; ++kb) {
+      const f32x4 x = *(const f32x4*)(lb + kb * 64);
+      f32x4 xs = x;
+      if constexpr (FO) {
+        const int c = ch0 + kb * 16 + 4 * g4;   // image channel of this lane's 4 values
+        const uint32_t nib = (sgl[(c >> 5) - w0] >> (c & 31)) & 15u;
+        xs = xor4(x, lut[nib]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        accm = mfma4(wa[kb][j], x[j], accm);
+        if constexpr (FO) accp = mfma4(wb[kb][j], xs[j], accp);
+      }
+    }
+    // next step's rows: written after this step's operand reads were issued, loads of the step after that behind them;
+    // the partial-sum stores come last (the staging never waits on a store it has just issued)
+    if (t + 1 < nsteps) put(t + 1);
+    if (t + 2 < nsteps) fetch(t + 2);
+    const int b = b0 + t * FDF_ROWS + mh * 16 + i16;
+    f32x4 v = accm;
+    if constexpr (FO) {
+      const int n = nt * 16 + 4 * g4;
+      const uint32_t nib = (sgl[9 + (n >> 5)] >> (n & 31)) & 15u;
+      const f32x4 ps = xor4(accp, lut[nib]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += ps[r];
+    }
+    if (b < b1) *(f32x4*)(A.slab + chunk * A.slab_stride + ((long)s * A.B + b) * 64 + nt * 16 + 4 * g4) = v;
+    lds_barrier();
+  }
+}
+
+// ==========================================================================================
+// backward of that layer, two launches over the same (particle, chunk, row range) grid:
+//   densef_dx_kernel : dX[R][c] = sum_n dz[R][n] W[n][c]  (+ Flipout: s_in[R][c] sum_n (s_out dz)[R][n] dW[n][c]);
+//                      dz = dH [H > 0] is built while staging; transposed weight fragments in registers
+//   densef_dw_kernel : dW[n][c] = sum_R dz[R][n] X[R][c]  (+ Flipout: sum_R (s_out dz)[R][n] (s_in X)[R][c]: the signs are
+//                      per row here, so the second product is a contraction of its own); tiles in registers across the rows
+// ==========================================================================================
+struct DfBwdArgs {
+  const float* x;                       // [S*B][x_ctot]
+  int x_ctot;
+  const float* h; const float* dh;      // [S*B][64]: the layer's output (after ReLU) and its gradient
+  const float* wat; const float* wbt;   // transposed images [cin][KPt] (offset to the layer)
+  long stride_at, stride_bt;
+  int KPt;
+  const uint32_t* sg_in; const uint32_t* sg_out;
+  int siw, sow;
+  float* dx;                            // [S*B][x_ctot]
+  float* gw_a; float* gw_b; float* gb_a;   // per-particle gradient images of the layer (forward layout [64][KP]) / bias gradients
+  long gw_stride; int gb_stride;
+  int KP;
+  int S, B, nchunk, nrs, rows_per_wg;
+};
+
+enum {
+  FDX_RSZ = 64 * 4 + 32,                        // 288 bytes: pitch 18 (row reads)
+  FDX_O_DZS = FDF_ROWS * FDX_RSZ, FDX_O_SG = 2 * FDF_ROWS * FDX_RSZ,
+  FDX_SLOT = FDX_O_SG + FDF_ROWS * FDF_SGW * 4,    // 19,968
+  FDX_O_LUT = FDF_NSLOT * FDX_SLOT,
+  FDX_LDS = FDX_O_LUT + 32 * 16,
+  DWF_RSX = FDF_CH * 4,                         // 960 bytes = 240 words = 48 (mod 64): column reads hit disjoint bank groups
+  DWF_RSZ = 80 * 4,                            // 320 bytes = 80 words = 16 (mod 64)
+  DWF_O_DZ = FDF_ROWS * DWF_RSX, DWF_O_DZS = DWF_O_DZ + FDF_ROWS * DWF_RSZ, DWF_O_SG = DWF_O_DZS + FDF_ROWS * DWF_RSZ,
+  DWF_SLOT = DWF_O_SG + FDF_ROWS * FDF_SGW * 4,  // 52,736
+  DWF_LDS = 2 * DWF_SLOT
+};
+
+// dz = dH [H > 0] of 4 couts of one row (+ its s_out copy): the staging unit of both backward kernels
+struct DzStage {
+  tf_u32x4 g, y;
+  uint32_t so;
+  int row, c4;
+  __device__ __forceinline__ void setup(int tid) { row = tid >> 4; c4 = tid & 15; }
+  template <bool FO>
+  __device__ __forceinline__ void fetch(const DfBwdArgs& A, int s, int bb) {
+    const long R = (long)s * A.B + min(bb + row, A.B - 1);
+    g = *(const tf_u32x4*)(A.dh + R * 64 + c4 * 4);
+    y = *(const tf_u32x4*)(A.h + R * 64 + c4 * 4);
+    if constexpr (FO) so = A.sg_out[R * A.sow + (c4 >> 3)];
+  }
+  template <bool FO>
+  __device__ __forceinline__ void put(char* dz, char* dzs, int pitch, bool live) const {
+    tf_u32x4 d = g;
+    const f32x4 yy = __builtin_bit_cast(f32x4, y);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = (live && yy[e] > 0.f) ? d[e] : 0u;
+    *(tf_u32x4*)(dz + row * pitch + c4 * 16) = d;
+    if constexpr (FO) {
+      const uint32_t nib = (so >> ((c4 & 7) * 4)) & 15u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] ^= ((nib >> e) & 1u) << 31;
+      *(tf_u32x4*)(dzs + row * pitch + c4 * 16) = d;
+    }
+  }
+};
+
+template <int EM>
+__global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0t = wave & 3, mh = wave >> 2;   // c-tiles c0t, c0t + 4, c0t + 8, c0t + 12 (< 15); row half
+  int bid = blockIdx.x;
+  const int rs = bid % A.nrs;
+  bid /= A.nrs;
+  const int chunk = bid % A.nchunk, s = bid / A.nchunk;
+  if (s >= A.S) return;
+  const int b0 = rs * A.rows_per_wg, b1 = min(A.B, b0 + A.rows_per_wg);
+  const int nsteps = (b1 - b0 + FDF_ROWS - 1) / FDF_ROWS;
+  const int ch0 = chunk * FDF_CH, w0 = ch0 >> 5;
+  build_sign_lut_f32((uint4*)(smem + FDX_O_LUT), tid);
+  f32x4 wa[4][4], wb[FO ? 4 : 1][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int ct = min(c0t + 4 * m, FDF_KB - 1);
+    const long ro = (long)(ch0 + ct * 16 + i16) * A.KPt + 4 * g4;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      wa[m][kb] = *(const f32x4*)(A.wat + A.stride_at * s + ro + kb * 16);
+      if constexpr (FO) wb[m][kb] = *(const f32x4*)(A.wbt + A.stride_bt * s + ro + kb * 16);
+    }
+  }
+  DzStage zs;
+  zs.setup(tid);
+  const int sq_row = tid / 9, sq_w = tid - sq_row * 9;
+  const bool sq_on = FO && tid < FDF_ROWS * 9;
+  uint32_t sw = 0;
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const int bb = b0 + t * FDF_ROWS;
+    zs.fetch<FO>(A, s, bb);
+    if constexpr (FO) {
+      if (sq_on) sw = A.sg_in[((long)s * A.B + min(bb + sq_row, A.B - 1)) * A.siw + min(w0 + sq_w, A.siw - 1)];
+    }
+  };
+  auto put = [&](int t) __attribute__((always_inline)) {
+    char* sl = smem + (t % FDF_NSLOT) * FDX_SLOT;
+    zs.put<FO>(sl, sl + FDX_O_DZS, FDX_RSZ, b0 + t * FDF_ROWS + zs.row < b1);
+    if constexpr (FO) {
+      if (sq_on) ((uint32_t*)(sl + FDX_O_SG))[sq_row * FDF_SGW + sq_w] = sw;
+    }
+  };
+  if (nsteps > 0) fetch(0);
+  __syncthreads();
+  if (nsteps > 0) put(0);
+  if (nsteps > 1) fetch(1);
+  lds_barrier();
+  const uint4* lut = (const uint4*)(smem + FDX_O_LUT);
+  for (int t = 0; t < nsteps; ++t) {
+    const char* sl = smem + (t % FDF_NSLOT) * FDX_SLOT;
+    const char* lb = sl + (mh * 16 + i16) * FDX_RSZ + g4 * 16;
+    f32x4 accm[4], accp[FO ? 4 : 1];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      accm[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (FO) accp[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const f32x4 z = *(const f32x4*)(lb + kb * 64);
+      f32x4 zz = z;
+      if constexpr (FO) zz = *(const f32x4*)(lb + FDX_O_DZS + kb * 64);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if (c0t + 4 * m < FDF_KB) {
+            accm[m] = mfma4(wa[m][kb][j], z[j], accm[m]);
+            if constexpr (FO) accp[m] = mfma4(wb[m][kb][j], zz[j], accp[m]);
+          }
+        }
+    }
+    if (t + 1 < nsteps) put(t + 1);
+    if (t + 2 < nsteps) fetch(t + 2);
+    const int b = b0 + t * FDF_ROWS + mh * 16 + i16;
+    const uint32_t* sgl = (const uint32_t*)(sl + FDX_O_SG) + (mh * 16 + i16) * FDF_SGW;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int ct = c0t + 4 * m;
+      if (ct < FDF_KB) {
+        f32x4 v = accm[m];
+        const int c = ch0 + ct * 16 + 4 * g4;
+        if constexpr (FO) {
+          const uint32_t nib = (sgl[(c >> 5) - w0] >> (c & 31)) & 15u;
+          const f32x4 ps = xor4(accp[m], lut[nib]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += ps[r];
+        }
+        if (b < b1) *(f32x4*)(A.dx + ((long)s * A.B + b) * A.x_ctot + c) = v;
+      }
+    }
+    lds_barrier();
+  }
+}
+
+template <int EM>
+__global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g4 = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = wave & 3, cpar = wave >> 2;   // c-tiles cpar, cpar + 2, ... (< 15)
+  int bid = blockIdx.x;
+  const int rs = bid % A.nrs;
+  bid /= A.nrs;
+  const int chunk = bid % A.nchunk, s = bid / A.nchunk;
+  if (s >= A.S) return;
+  const int b0 = rs * A.rows_per_wg, b1 = min(A.B, b0 + A.rows_per_wg);
+  const int nsteps = (b1 - b0 + FDF_ROWS - 1) / FDF_ROWS;
+  const int ch0 = chunk * FDF_CH, w0 = ch0 >> 5;
+  {
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < DWF_LDS / 4; k += TF_THREADS) z[k] = 0u;
+  }
+  f32x4 acc_a[8], acc_b[FO ? 8 : 1];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    acc_a[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (FO) acc_b[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float bsum = 0.f;
+  // staging: X chunk [32][240] (4 chunks per thread), dz, sign words
+  int xq_row[4], xq_off[4], xq_dst[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = j * TF_THREADS + tid;
+    const int row = min(q / 60, FDF_ROWS - 1), c = q % 60;
+    xq_row[j] = q < FDF_ROWS * 60 ? row : -1;
+    xq_off[j] = ch0 * 4 + c * 16;
+    xq_dst[j] = row * DWF_RSX + c * 16;
+  }
+  DzStage zs;
+  zs.setup(tid);
+  const int sq_row = tid / 9, sq_w = tid - sq_row * 9;
+  const bool sq_on = FO && tid < FDF_ROWS * 9;
+  tf_u32x4 xr[4];
+  uint32_t sw = 0;
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const int bb = b0 + t * FDF_ROWS;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long R = (long)s * A.B + min(bb + max(xq_row[j], 0), A.B - 1);
+      xr[j] = *(const tf_u32x4*)((const char*)A.x + R * A.x_ctot * 4 + xq_off[j]);
+    }
+    zs.fetch<FO>(A, s, bb);
+    if constexpr (FO) {
+      if (sq_on) sw = A.sg_in[((long)s * A.B + min(bb + sq_row, A.B - 1)) * A.siw + min(w0 + sq_w, A.siw - 1)];
+    }
+  };
+  auto put = [&](int t) __attribute__((always_inline)) {
+    char* sl = smem + (t & 1) * DWF_SLOT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (xq_row[j] >= 0) *(tf_u32x4*)(sl + xq_dst[j]) = xr[j];
+    // rows past the end of the range carry dz = 0: their X rows (clamped copies) do not contribute
+    zs.put<FO>(sl + DWF_O_DZ, sl + DWF_O_DZS, DWF_RSZ, b0 + t * FDF_ROWS + zs.row < b1);
+    if constexpr (FO) {
+      if (sq_on) ((uint32_t*)(sl + DWF_O_SG))[sq_row * FDF_SGW + sq_w] = sw;
+    }
+  };
+  if (nsteps > 0) fetch(0);
+  __syncthreads();
+  if (nsteps > 0) put(0);
+  if (nsteps > 1) fetch(1);
+  lds_barrier();
+  for (int t = 0; t < nsteps; ++t) {
+    const char* sl = smem + (t & 1) * DWF_SLOT;
+    // the previous step's slot is free (barrier): stage the next rows first, the loads of the step after behind them
+    if (t + 1 < nsteps) put(t + 1);
+    if (t + 2 < nsteps) fetch(t + 2);
+    const char* zi = sl + DWF_O_DZ + g4 * DWF_RSZ + (nt * 16 + i16) * 4;
+    float bz[8], bzs[FO ? 8 : 1];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bz[ks] = *(const float*)(zi + 4 * ks * DWF_RSZ);
+      if constexpr (FO) bzs[ks] = *(const float*)(zi + (DWF_O_DZS - DWF_O_DZ) + 4 * ks * DWF_RSZ);
+    }
+    if (chunk == 0 && cpar == 0) {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) bsum += bz[ks];
+    }
+    const uint32_t* sgl = (const uint32_t*)(sl + DWF_O_SG) + g4 * FDF_SGW;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int ct = cpar + 2 * m;
+      if (ct < FDF_KB) {
+        const char* xi = sl + g4 * DWF_RSX + (ct * 16 + i16) * 4;
+        const int c = ch0 + ct * 16 + i16;
+        float ax[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) ax[ks] = *(const float*)(xi + 4 * ks * DWF_RSX);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          acc_a[m] = mfma4(ax[ks], bz[ks], acc_a[m]);
+          if constexpr (FO) {
+            const uint32_t bit = (sgl[4 * ks * FDF_SGW + (c >> 5) - w0] >> (c & 31)) & 1u;
+            acc_b[m] = mfma4(xor1(ax[ks], bit << 31), bzs[ks], acc_b[m]);
+          }
+        }
+      }
+    }
+    lds_barrier();
+  }
+  // ---- flush: transposed tiles (rows = input channels, columns = couts) into the particle's gradient image ----
+  const int n = nt * 16 + i16;
+  float* gwa = A.gw_a + A.gw_stride * s + (long)n * A.KP + ch0 + 4 * g4;
+  float* gwb = A.gw_b + A.gw_stride * s + (long)n * A.KP + ch0 + 4 * g4;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int ct = cpar + 2 * m;
+    if (ct < FDF_KB) {
+      if (A.nrs == 1) {
+        *(f32x4*)(gwa + ct * 16) = acc_a[m];
+        if constexpr (FO) *(f32x4*)(gwb + ct * 16) = acc_b[m];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(gwa + ct * 16 + r, acc_a[m][r]);
+          if constexpr (FO) atomicAdd(gwb + ct * 16 + r, acc_b[m][r]);
+        }
+      }
+    }
+  }
+  if (chunk == 0 && cpar == 0) {
+    float t = bsum;
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    if (g4 == 0) {
+      float* gb = A.gb_a + (long)A.gb_stride * s + n;
+      if (A.nrs == 1) *gb = t; else atomicAdd(gb, t);
+    }
   }
 }

@@ -144,6 +144,7 @@ struct BnnPlan {
   int mlp = 0;
   long slab_stride = 0;
   int slab_bstride = 0;
+  int slab_slots[3] = {0, 0, 0};                     // slabs allocated per group
   size_t o_layers, o_a_hi, o_a_lo, o_b, o_at, o_bt, o_bias_a, o_bias_b, o_gw_a, o_gw_b, o_gb_a, o_gb_b, o_eps, o_radr,
       o_norms, o_norm_part, o_sign_in, o_sign_out, o_acc, o_scal, o_preds, o_poolgrad, o_xplanes, o_amax, o_tens;
   size_t elem = 4;
@@ -407,14 +408,19 @@ static void layout_workspace(BnnPlan* p) {
   }
   // fused trunk dW: one partial image per workgroup, S * nsplit <= 256 (512 for the k3 / k5 kernel) whatever the call
   p->slab_stride = 0;
-  if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
+  if (p->d.net == BNN_NET_INCEPTION) {
+    // S * nsplit slabs per launch, nsplit = max(1, min(B, 256 (512) / S)): at most max(256 (512), S) whatever the call.
+    // The fp32 plan's two dW launches write disjoint layers of ONE slab set (group 0).
     p->slab_stride = rupl(p->layers[10].w_off, 64);
     p->slab_bstride = rup(p->layers[10].bias_off, 16);
-    const int slots[3] = {256, 256, 512};
+    const int ngrp = p->d.prec == BNN_PREC_BF16X3 ? 3 : 1;
     for (int g = 0; g < 3; ++g) {
-      p->o_slab_a[g] = take((size_t)slots[g] * p->slab_stride * 4);
-      p->o_slab_b[g] = take((size_t)slots[g] * p->slab_stride * 4);
-      p->o_slab_ba[g] = take((size_t)slots[g] * p->slab_bstride * 4);
+      p->slab_slots[g] = g < ngrp ? std::max(g == 2 ? 512 : 256, (int)p->d.max_particles) : 0;
+      const int gs = g < ngrp ? g : 0;
+      p->o_slab_a[g] = g < ngrp ? take((size_t)p->slab_slots[g] * p->slab_stride * 4) : p->o_slab_a[gs];
+      p->o_slab_b[g] = g < ngrp ? take((size_t)p->slab_slots[g] * p->slab_stride * 4) : p->o_slab_b[gs];
+      p->o_slab_ba[g] = g < ngrp ? take((size_t)p->slab_slots[g] * p->slab_bstride * 4) : p->o_slab_ba[gs];
+      if (g >= ngrp) p->slab_slots[g] = p->slab_slots[gs];
     }
   }
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_LINEAR && p->layers[0].KP == ML_K0 && p->layers[0].cout == ML_N0 &&
@@ -422,6 +428,10 @@ static void layout_workspace(BnnPlan* p) {
     p->mlp = 1;
     p->o_mlp_x = take((size_t)p->d.max_batch * ML_K0 * 2);
     p->o_mlp_dz4 = take((size_t)cap * 8 * 2 * 2);
+  }
+  if (p->d.prec == BNN_PREC_F32 && p->d.net == BNN_NET_INCEPTION && p->layers[10].cin % FDF_CH == 0) {
+    p->dks_rows = cap;
+    p->o_dks = take((size_t)(p->layers[10].cin / FDF_CH) * cap * 64 * 4);   // partial pre-activations of densef_fwd_kernel
   }
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
     p->o_mact1 = take((size_t)cap * p->d.win_length * 16);
@@ -1139,11 +1149,16 @@ static int launch_conv_dw_mw_lrt(const GroupArgs& A, const ConvDwPlan& D, int ld
   return 0;
 }
 
+static int check_slab_slots(const BnnPlan* p, const Ctx* c, int g, int nsplit) {
+  if ((long)c->S * nsplit > p->slab_slots[g])
+    return fail(BNN_E_INVALID, "dW partial images: %d particles x %d splits exceed the %d slabs of this plan", c->S, nsplit, p->slab_slots[g]);
+  return 0;
+}
 // partial images ("slabs") for the per-group conv dW kernels of the Inception net: the trunk kernels' workspace and layout
-static bool conv_dw_slabs(const BnnPlan* p, int gi) { return p->slab_stride > 0 && p->d.net == BNN_NET_INCEPTION && gi < 3; }
+static bool conv_dw_slabs(const BnnPlan* p, int gi) { return p->slab_stride > 0 && p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION && gi < 3; }
 static int conv_dw_nsplit(const Ctx* c) { return std::max(1, std::min(c->B, 256 / std::max(1, c->S))); }
 
-static int launch_conv_dw_mw(BnnPlan* p, const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
+static int launch_conv_dw_mw(BnnPlan* p, const Ctx* c_for_slabs, const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   if (em != EM_LRT) return fail(BNN_E_INVALID, "per-group conv dW: estimator %d is covered by the trunk kernels", em);
   static thread_local ConvDwPlan D, H;
@@ -1154,6 +1169,7 @@ static int launch_conv_dw_mw(BnnPlan* p, const GroupArgs& A0, const LayerDesc* l
     return fail(BNN_E_INVALID, "conv dW staging plan exceeds the compiled unit counts");
   D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
   if (conv_dw_slabs(p, gi)) {
+    BNN_TRY(check_slab_slots(p, c_for_slabs, gi, D.nsplit));
     D.slab_a = ws_f(p, p->o_slab_a[gi]);
     D.slab_b = ws_f(p, p->o_slab_b[gi]);
     D.slab_stride = p->slab_stride;
@@ -1702,6 +1718,7 @@ static int launch_trunk_dw1(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   T.gw_stride = p->slab_stride; T.gb_stride = p->slab_bstride;
   T.S = c->S; T.B = c->B; T.L = p->d.win_length;
   T.nsplit = trunk_dw_nsplit(c, 0);
+  BNN_TRY(check_slab_slots(p, c, 0, T.nsplit));
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DW, 0, c->st);
   ps_.name("trunk_dw1_kernel<%d>", c->em);
@@ -1730,6 +1747,7 @@ static int launch_trunk_dw2(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
   T.S = c->S; T.B = c->B; T.L = p->d.win_length;
   // kind 1 workgroups are small (6 waves, 52 KB of LDS): two share a CU
   T.nsplit = trunk_dw_nsplit(c, sg);
+  BNN_TRY(check_slab_slots(p, c, sg, T.nsplit));
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DW, kind == 0 ? 1 : 2, c->st);
   ps_.name(kind == 0 ? "trunk_dw2a_kernel<%d>" : "trunk_dw2b_kernel<%d>", c->em);
@@ -1865,6 +1883,9 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
   return 0;
 }
 
+static bool densef_ok(const BnnPlan* p, const Ctx* c, const GroupArgs& A);
+static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi);
+
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
   const bool tf = tf_ok(p, c);
@@ -1890,7 +1911,9 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
   for (int gi = trunk ? 3 : 0; gi < p->n_groups; ++gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, x, &A);
-    if (!bf)
+    if (!bf && densef_ok(p, c, A))
+      BNN_TRY(launch_densef_fwd(p, A, c->em, c->st, &p->prof, gi));
+    else if (!bf)
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
       BNN_TRY(launch_conv_fwd_dma(A, p->layers, c->em, c->st, &p->prof, gi));
@@ -1907,6 +1930,225 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
   }
   p->last_S = c->S;
   p->last_B = c->B;
+  return 0;
+}
+
+// fused fp32 trunk dX (kernels_f32.h): dz of MID and of ACT1 from dY(ACT2), groups 2 and 1 in one launch
+static int tf_nsplit(const Ctx* c) { return std::max(1, std::min(c->B, 256 / std::max(1, c->S))); }
+
+static int launch_tf_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, bool premasked) {
+  GroupArgs G;
+  fill_group_args(p, a, c, 1, a->x, &G);
+  BNN_TRY(tf_check_tables(p));
+  TfDxArgs T{};
+  T.g_act2 = tens_ptr(p, TI_ACT2, 1);
+  T.g_act2m = tens_ptr(p, TI_ACT2, 1);
+  T.act2 = tens_ptr(p, TI_ACT2, 0);
+  T.amax = (const unsigned char*)p->bufs.workspace + p->o_amax;
+  T.m_act1 = (const unsigned char*)p->bufs.workspace + p->o_mact1;
+  T.m_mid = (const unsigned char*)p->bufs.workspace + p->o_mmid;
+  T.g_mid = tens_ptr(p, TI_MID, 1);
+  T.g_act1 = tens_ptr(p, TI_ACT1, 1);
+  T.ws = G.ws;
+  T.layers = G.layers;
+  T.sign_in = c->nz.sign_in;
+  T.sign_out = c->nz.sign_out;
+  T.examples = (long)c->S * c->B;
+  T.S = c->S;
+  T.B = c->B;
+  T.L = p->d.win_length;
+  T.nsplit = tf_nsplit(c);
+  static_assert(TD_LDS <= 160 * 1024, "LDS budget");
+  const unsigned grid = (unsigned)(c->S * T.nsplit);
+  ProfScope ps_(&p->prof, PK_DX, 1, c->st);
+  ps_.name("tf_dx_kernel<%d, %s>", c->em, premasked ? "true" : "false");
+  BNN_DRY_RETURN();
+#define LAUNCH_TFDX(EMV, PREV)                                                             \
+  do {                                                                                     \
+    BNN_TRY(set_lds((tf_dx_kernel<EMV, PREV>), TD_LDS));                                   \
+    tf_dx_kernel<EMV, PREV><<<dim3(grid), dim3(TF_THREADS), TD_LDS, c->st>>>(T);           \
+  } while (0)
+  if (c->em == EM_FLIPOUT) {
+    if (premasked) LAUNCH_TFDX(EM_FLIPOUT, true); else LAUNCH_TFDX(EM_FLIPOUT, false);
+  } else {
+    if (premasked) LAUNCH_TFDX(EM_PLAIN, true); else LAUNCH_TFDX(EM_PLAIN, false);
+  }
+#undef LAUNCH_TFDX
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// fp32 trunk dW (kernels_f32.h): kind 0 = block 1 + the k3 / k5 level, kind 1 = the 1x1 level; one slab set
+static int launch_tf_dw(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int kind) {
+  GroupArgs G;
+  fill_group_args(p, a, c, 0, a->x, &G);
+  TfDwArgs T{};
+  const float* xp = (const float*)((char*)p->bufs.workspace + p->o_xplanes);
+  T.xp[0] = xp;
+  T.xp[1] = xp + (size_t)p->d.max_batch * p->d.win_length * TF_XC;
+  T.act1 = tens_ptr(p, TI_ACT1, 0);
+  T.mid = tens_ptr(p, TI_MID, 0);
+  T.g_act1 = tens_ptr(p, TI_ACT1, 1);
+  T.g_mid = tens_ptr(p, TI_MID, 1);
+  T.g_act2 = tens_ptr(p, TI_ACT2, 1);
+  T.layers = G.layers;
+  T.sign_in = c->nz.sign_in;
+  T.sign_out = c->nz.sign_out;
+  T.examples = (long)c->S * c->B;
+  T.gw_a = ws_f(p, p->o_slab_a[0]); T.gw_b = ws_f(p, p->o_slab_b[0]); T.gb_a = ws_f(p, p->o_slab_ba[0]);
+  T.gw_stride = p->slab_stride; T.gb_stride = p->slab_bstride;
+  T.S = c->S; T.B = c->B; T.L = p->d.win_length;
+  T.nsplit = tf_nsplit(c);
+  BNN_TRY(check_slab_slots(p, c, 0, T.nsplit));
+  static_assert(tw_lds<0>() <= 160 * 1024 && tw_lds<1>() <= 160 * 1024, "LDS budgets");
+  if (T.L * 84 > TFW_NLD * TF_THREADS) return fail(BNN_E_INVALID, "fp32 trunk dW: window too long for the staging plan");
+  const unsigned grid = (unsigned)(c->S * T.nsplit);
+  ProfScope ps_(&p->prof, PK_DW, kind == 0 ? 0 : 1, c->st);
+  ps_.name("tf_dw_kernel<%d, %d>", c->em, kind);
+  BNN_DRY_RETURN();
+#define LAUNCH_TFDW(EMV, KV)                                                                        \
+  do {                                                                                              \
+    BNN_TRY(set_lds((tf_dw_kernel<EMV, KV>), tw_lds<KV>()));                                        \
+    tf_dw_kernel<EMV, KV><<<dim3(grid), dim3(TF_THREADS), tw_lds<KV>(), c->st>>>(T);                \
+  } while (0)
+  if (c->em == EM_FLIPOUT) {
+    if (kind == 0) LAUNCH_TFDW(EM_FLIPOUT, 0); else LAUNCH_TFDW(EM_FLIPOUT, 1);
+  } else {
+    if (kind == 0) LAUNCH_TFDW(EM_PLAIN, 0); else LAUNCH_TFDW(EM_PLAIN, 1);
+  }
+#undef LAUNCH_TFDW
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// the wide dense layer of the Inception net on the fp32 plan: K-split, weight-stationary (kernels_f32.h)
+static bool densef_ok(const BnnPlan* p, const Ctx* c, const GroupArgs& A) {
+  if (!tf_ok(p, c) || p->o_dks == 0 || !A.g.is_dense || A.g.n_branch != 1 || A.g.in_bcast) return false;
+  const BranchDesc& br = A.g.br[0];
+  const LayerDesc& ly = p->layers[br.layer];
+  return br.cout == 64 && br.n_off == 0 && br.in_off == 0 && br.out_off == 0 && br.cin_p == ly.cin && ly.cin % FDF_CH == 0 &&
+         ly.KP == ly.cin && ly.KPt == 64 && A.t[A.g.in_t].ctot == ly.cin && A.t[br.out_t].ctot == 64 && br.relu &&
+         (long)A.cg.S * A.cg.B <= p->dks_rows && ly.sign_out_words == 2 && (ly.w_off & 3) == 0 && (ly.wt_off & 3) == 0;
+}
+
+static void densef_geometry(const GroupArgs& A, int nchunk, int max_rs, int* nrs, int* rows_per_wg) {
+  const int steps = (A.cg.B + FDF_ROWS - 1) / FDF_ROWS;
+  int r = std::max(1, std::min(steps, 256 / std::max(1, A.cg.S * nchunk)));
+  r = std::min(r, max_rs);
+  *nrs = r;
+  *rows_per_wg = ((steps + r - 1) / r) * FDF_ROWS;
+}
+
+static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi) {
+  const BranchDesc& br = A.g.br[0];
+  const LayerDesc& ly = p->layers[br.layer];
+  DfArgs F{};
+  F.x = (const float*)A.t[A.g.in_t].p;
+  F.x_ctot = A.t[A.g.in_t].ctot;
+  F.wa = (const float*)A.ws.a_hi + ly.w_off;
+  F.wb = (const float*)A.ws.b + ly.w_off;
+  F.stride_a = A.ws.slot_stride_a;
+  F.stride_b = A.ws.slot_stride_b;
+  F.KP = ly.KP;
+  F.sg_in = A.nz.sign_in + ly.sign_in_off * A.nz.examples;
+  F.sg_out = A.nz.sign_out + ly.sign_out_off * A.nz.examples;
+  F.siw = ly.sign_in_words;
+  F.sow = ly.sign_out_words;
+  F.slab = ws_f(p, p->o_dks);
+  F.slab_stride = (long)A.cg.S * A.cg.B * 64;
+  F.S = A.cg.S;
+  F.B = A.cg.B;
+  F.nchunk = ly.cin / FDF_CH;
+  densef_geometry(A, F.nchunk, 1 << 20, &F.nrs, &F.rows_per_wg);
+  static_assert(FDF_LDS <= 160 * 1024 && FDX_LDS <= 160 * 1024 && DWF_LDS <= 160 * 1024, "LDS budgets");
+  const unsigned grid = (unsigned)(F.S * F.nchunk * F.nrs);
+  ProfScope ps_(pf, PK_FWD, gi, st);
+  ps_.name("densef_fwd_kernel<%d>", em);
+  BNN_DRY_RETURN();
+  if (em == EM_PLAIN) {
+    BNN_TRY(set_lds(densef_fwd_kernel<EM_PLAIN>, FDF_LDS));
+    densef_fwd_kernel<EM_PLAIN><<<dim3(grid), dim3(TF_THREADS), FDF_LDS, st>>>(F);
+  } else {
+    BNN_TRY(set_lds(densef_fwd_kernel<EM_FLIPOUT>, FDF_LDS));
+    densef_fwd_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TF_THREADS), FDF_LDS, st>>>(F);
+  }
+  DenseKsFinArgs R{};
+  R.slab = F.slab;
+  R.slab_stride = F.slab_stride;
+  R.nchunk = F.nchunk;
+  R.rows = A.cg.S * A.cg.B;
+  R.B = A.cg.B;
+  R.bias = A.ws.bias_a + ly.bias_off + br.n_off;
+  R.bias_stride = A.ws.bias_stride_a;
+  R.relu = br.relu;
+  R.out = A.t[br.out_t];
+  R.out_off = br.out_off;
+  const unsigned fgrid = (unsigned)((R.rows * 16 + 255) / 256);
+  dense_ks_fin_kernel<EM_PLAIN><<<dim3(fgrid), dim3(256), 0, st>>>(R);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi) {
+  const BranchDesc& br = A.g.br[0];
+  const LayerDesc& ly = p->layers[br.layer];
+  DfBwdArgs F{};
+  F.x = (const float*)A.t[A.g.in_t].p;
+  F.x_ctot = A.t[A.g.in_t].ctot;
+  F.h = (const float*)A.t[br.out_t].p;
+  F.dh = (const float*)A.t[br.out_t + T_GRAD].p;
+  F.wat = (const float*)A.ws.at + ly.wt_off;
+  F.wbt = (const float*)A.ws.bt + ly.wt_off;
+  F.stride_at = A.ws.slott_stride_a;
+  F.stride_bt = A.ws.slott_stride_b;
+  F.KPt = ly.KPt;
+  F.sg_in = A.nz.sign_in + ly.sign_in_off * A.nz.examples;
+  F.sg_out = A.nz.sign_out + ly.sign_out_off * A.nz.examples;
+  F.siw = ly.sign_in_words;
+  F.sow = ly.sign_out_words;
+  F.dx = (float*)A.t[br.dx_t].p;
+  F.gw_a = A.gw_a + ly.w_off;
+  F.gw_b = A.gw_b + ly.w_off;
+  F.gb_a = A.gb_a + ly.bias_off;
+  F.gw_stride = A.gw_stride;
+  F.gb_stride = A.gb_stride;
+  F.KP = ly.KP;
+  F.S = A.cg.S;
+  F.B = A.cg.B;
+  F.nchunk = ly.cin / FDF_CH;
+  if (br.dx_t < 0 || A.t[br.dx_t].ctot != F.x_ctot) return fail(BNN_E_INVALID, "fp32 dense backward: gradient tensor shape");
+  {
+    // dW: at most two row ranges per (particle, chunk) - two float atomics per element onto the zeroed images commute
+    densef_geometry(A, F.nchunk, 2, &F.nrs, &F.rows_per_wg);
+    const unsigned grid = (unsigned)(F.S * F.nchunk * F.nrs);
+    ProfScope ps_(pf, PK_DW, gi, st);
+    ps_.name("densef_dw_kernel<%d>", em);
+    if (!g_dry) {
+      if (em == EM_PLAIN) {
+        BNN_TRY(set_lds(densef_dw_kernel<EM_PLAIN>, DWF_LDS));
+        densef_dw_kernel<EM_PLAIN><<<dim3(grid), dim3(TF_THREADS), DWF_LDS, st>>>(F);
+      } else {
+        BNN_TRY(set_lds(densef_dw_kernel<EM_FLIPOUT>, DWF_LDS));
+        densef_dw_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TF_THREADS), DWF_LDS, st>>>(F);
+      }
+    }
+  }
+  {
+    densef_geometry(A, F.nchunk, 1 << 20, &F.nrs, &F.rows_per_wg);
+    const unsigned grid = (unsigned)(F.S * F.nchunk * F.nrs);
+    ProfScope ps_(pf, PK_DX, gi, st);
+    ps_.name("densef_dx_kernel<%d>", em);
+    if (!g_dry) {
+      if (em == EM_PLAIN) {
+        BNN_TRY(set_lds(densef_dx_kernel<EM_PLAIN>, FDX_LDS));
+        densef_dx_kernel<EM_PLAIN><<<dim3(grid), dim3(TF_THREADS), FDX_LDS, st>>>(F);
+      } else {
+        BNN_TRY(set_lds(densef_dx_kernel<EM_FLIPOUT>, FDX_LDS));
+        densef_dx_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TF_THREADS), FDX_LDS, st>>>(F);
+      }
+    }
+  }
+  if (!g_dry) HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -2001,6 +2243,16 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   for (int gi = p->n_groups - 1 - (c->last_fused ? 1 : 0); gi >= 0; --gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
+    if (!A.g.is_dense && tf_ok(p, c)) {
+      // fp32 conv trunk: dz of MID / ACT1 (and the masked dz of ACT2), then the two dW launches and the slab reduction
+      if (gi == 2) {
+        BNN_TRY(launch_tf_dx(p, a, c, act2_premasked));
+        BNN_TRY(launch_tf_dw(p, a, c, 0));
+        BNN_TRY(launch_tf_dw(p, a, c, 1));
+        BNN_TRY(reduce_trunk_slabs(p, c));
+      }
+      continue;
+    }
     if (!A.g.is_dense && trunk_ok(p, c)) {
       // conv trunk: dz of MID / ACT1 (and the masked dz of ACT2) first, then the three dW kernels
       if (gi == 2) {
@@ -2019,11 +2271,15 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       act2_premasked = true;   // its dX is stored masked with [input > 0]
       continue;
     }
+    if (p->d.prec == BNN_PREC_F32 && densef_ok(p, c, A) && A.g.br[0].dx_t >= 0) {
+      BNN_TRY(launch_densef_bwd(p, A, c->em, c->st, &p->prof, gi));
+      continue;
+    }
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
     else if (!A.g.is_dense)
       {
-      BNN_TRY(launch_conv_dw_mw(p, A, p->layers, c->em, c->st, &p->prof, gi));
+      BNN_TRY(launch_conv_dw_mw(p, c, A, p->layers, c->em, c->st, &p->prof, gi));
       if (gi == 0 && conv_dw_slabs(p, 0)) BNN_TRY(reduce_trunk_slabs(p, c));
     }
     else if (A.g.n_branch == 1 && !A.g.in_bcast && A.g.br[0].cout <= 64 && (A.g.br[0].cout % 8) == 0 &&
@@ -2088,7 +2344,7 @@ static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c) {
     R = SlabReduceArgs{};
     for (int g = 0; g < 3; ++g) {
       R.slab[g] = ws_f(p, which == 0 ? p->o_slab_a[g] : (which == 1 ? p->o_slab_b[g] : p->o_slab_ba[g]));
-      R.n[g] = c->em == EM_LRT ? conv_dw_nsplit(c) : trunk_dw_nsplit(c, g);
+      R.n[g] = p->d.prec == BNN_PREC_F32 ? tf_nsplit(c) : (c->em == EM_LRT ? conv_dw_nsplit(c) : trunk_dw_nsplit(c, g));
     }
     R.stride = which == 2 ? p->slab_bstride : p->slab_stride;
     for (int l = 0; l < 10; ++l) R.lay_end[l] = which == 2 ? p->layers[l + 1].bias_off : p->layers[l + 1].w_off;
