@@ -12,7 +12,9 @@
 //
 // Reference arithmetic: nets/inception.py:10-132 (both inception blocks), [3P] tyxe.poutine.flipout (bayesian.py:68-69).
 #pragma once
-#include "kernels_trunk.h"
+#include "kernels_misc.h"
+#include "kernels_trunk_dw.h"   // kernels_trunk.h (tl_* tables, rot16, lds_barrier) and what kernels_dense_ks.h needs
+#include "kernels_dense_ks.h"   // HL_ROWS, DenseKsFinArgs
 
 enum { TF_WAVES = 8, TF_THREADS = TF_WAVES * 64 };
 enum {
@@ -51,6 +53,7 @@ struct TfArgs {
   unsigned char* amax;       // [S*B*L][32] 2-bit arg-max codes of block 2's pooled branch, 4 channels per byte (training step only)
   unsigned char* m_act1;     // [S*B*L][32] ReLU masks [ACT1 > 0], 4 channels per byte (low nibble)
   unsigned char* m_mid;      // [S*B*L][32] [MID > 0]
+  unsigned char* m_act2;     // [S*B*L][20] [ACT2 > 0] (the dense layer's dX applies it)
   int S, B, L, nsplit;
 };
 
@@ -196,6 +199,10 @@ struct TfJobRun {
           }
         } else {
           *(f32x4*)((char*)A.act2 + ((R0 + (unsigned)row) * 320u + (unsigned)((OOFF + chb) * 4))) = v[mt];
+          if constexpr (TRAIN) {
+            const uint32_t bits = (v[mt][0] > 0.f ? 1u : 0u) | (v[mt][1] > 0.f ? 2u : 0u) | (v[mt][2] > 0.f ? 4u : 0u) | (v[mt][3] > 0.f ? 8u : 0u);
+            A.m_act2[(R0 + (unsigned)row) * 20u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)bits;
+          }
         }
       }
     }
@@ -436,7 +443,8 @@ enum {
   TD_O_DZM = 3 * TD_P2,                // [2 bufs]
   TD_O_SGN = TD_O_DZM + 2 * TD_PM,     // [3 slots][80 words]
   TD_O_LUT = TD_O_SGN + 3 * 80 * 4,
-  TD_LDS = TD_O_LUT + 32 * 16
+  TD_O_MSK = TD_O_LUT + 32 * 16,       // [3 slots][m_mid | m_act1 | amax][1024]: the window's mask / code bytes (L x 32 B each)
+  TD_LDS = TD_O_MSK + 3 * 3 * 1024
 };
 
 struct TfDxArgs {
@@ -489,13 +497,10 @@ struct TdJobA {
     const uint32_t* sg = (const uint32_t*)(smem + TD_O_SGN) + (k % 3) * 80 + LY * 8;
     char* dzm = smem + TD_O_DZM + (k & 1) * TD_PM;
     const int och = MCH + 4 * g4;   // MID channel of this lane's 4 outputs
-    // the ReLU masks of the tile's outputs are fetched ahead of the MFMAs
+    const unsigned char* msl = (const unsigned char*)(smem + TD_O_MSK + (k % 3) * 3072);
     uint32_t mb[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int row = min(mt * 16 + i16, L - 1);
-      mb[mt] = A.m_mid[(R0 + (unsigned)row) * 32u + (unsigned)(och >> 2)];
-    }
+    for (int mt = 0; mt < 2; ++mt) mb[mt] = msl[(mt * 16 + i16) * 32 + (och >> 2)];
     uint4 fm = make_uint4(0, 0, 0, 0);
     if constexpr (FO) {
       const int ci = J * 16 + i16;   // input channel of the layer = row of the transposed fragment
@@ -561,13 +566,13 @@ struct TdJobB {
     const char* dzm = smem + TD_O_DZM + (k & 1) * TD_PM;
     const uint4* lut = (const uint4*)(smem + TD_O_LUT);
     const int och = CT * 16 + 4 * g4, ci = CT * 16 + i16;
+    const unsigned char* msl = (const unsigned char*)(smem + TD_O_MSK + (k % 3) * 3072);
     uint32_t mb[2], code[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int row = mt * 16 + i16;
-      const unsigned o = (R0 + (unsigned)min(row, L - 1)) * 32u + (unsigned)(och >> 2);
-      mb[mt] = A.m_act1[o];
-      code[mt] = row < L ? (uint32_t)A.amax[o] : 0x55u;
+      mb[mt] = msl[1024 + row * 32 + (och >> 2)];
+      code[mt] = row < L ? (uint32_t)msl[2048 + row * 32 + (och >> 2)] : 0x55u;
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 accp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -646,7 +651,10 @@ template <bool FO, bool PRE>
 struct TdLoader {
   int qo[3], dst[3];
   bool on[3];
-  tf_u32x4 g[3], y[PRE ? 1 : 3];
+  tf_u32x4 g[3], y[PRE ? 1 : 3], mk;
+  const unsigned char* msrc;
+  int mdst;
+  bool mon;
   const uint32_t* sg0 = nullptr;
   const uint32_t* sg1 = nullptr;
   long sst0 = 0, sst1 = 0;
@@ -665,6 +673,13 @@ struct TdLoader {
       const int qq = on[j] ? q : 0;
       qo[j] = qq * 16;
       dst[j] = (qq / 20 + HALO) * TD_RS2 + (qq % 20) * 16;
+    }
+    {
+      // mask / code bytes of a window: 3 planes x L x 32 B, one 16-byte chunk per loader lane
+      const int ll = p * 64 + lane, pl = min(ll / 60, 2), c = ll - (ll / 60) * 60;
+      mon = ll < 180 && c * 16 < A.L * 32;
+      msrc = (pl == 0 ? A.m_mid : (pl == 1 ? A.m_act1 : A.amax)) + (mon ? c * 16 : 0);
+      mdst = pl * 1024 + c * 16;
     }
     if constexpr (FO) {
       if (p == 0) {
@@ -692,6 +707,7 @@ struct TdLoader {
 #pragma unroll
       for (int j = 0; j < 3; ++j) y[j] = *(const tf_u32x4*)(yp + qo[j]);
     }
+    mk = *(const tf_u32x4*)(msrc + (Rs + k * Rstep) * 32);
     if constexpr (FO) {
       if (sg0) sb0 = sg0[(long)k * sst0];
       if (sg1) sb1 = sg1[(long)k * sst1];
@@ -713,6 +729,7 @@ struct TdLoader {
         *(tf_u32x4*)(sl + dst[j]) = d;
       }
     }
+    if (mon) *(tf_u32x4*)(smem + TD_O_MSK + (k % 3) * 3072 + mdst) = mk;
     if constexpr (FO) {
       if (p == 0) {
         uint32_t* sgw = (uint32_t*)(smem + TD_O_SGN) + (k % 3) * 80;
@@ -1259,6 +1276,7 @@ struct DfBwdArgs {
   const uint32_t* sg_in; const uint32_t* sg_out;
   int siw, sow;
   float* dx;                            // [S*B][x_ctot]
+  const unsigned char* m_x;             // [S*B][x_ctot / 4] nibble masks [X > 0] of the layer's input (null: dX is stored unmasked)
   float* gw_a; float* gw_b; float* gb_a;   // per-particle gradient images of the layer (forward layout [64][KP]) / bias gradients
   long gw_stride; int gb_stride;
   int KP;
@@ -1362,6 +1380,13 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
   for (int t = 0; t < nsteps; ++t) {
     const char* sl = smem + (t % FDF_NSLOT) * FDX_SLOT;
     const char* lb = sl + (mh * 16 + i16) * FDX_RSZ + g4 * 16;
+    uint32_t mxb[4] = {15u, 15u, 15u, 15u};
+    if (A.m_x) {
+      const long R = (long)s * A.B + min(b0 + t * FDF_ROWS + mh * 16 + i16, A.B - 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        mxb[m] = A.m_x[R * (A.x_ctot >> 2) + ((ch0 + min(c0t + 4 * m, FDF_KB - 1) * 16) >> 2) + g4];
+    }
     f32x4 accm[4], accp[FO ? 4 : 1];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -1399,6 +1424,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += ps[r];
         }
+        if (A.m_x) v = mask4(v, mxb[m]);   // the layer's input is a ReLU output: its gradient is wanted where it is positive only
         if (b < b1) *(f32x4*)(A.dx + ((long)s * A.B + b) * A.x_ctot + c) = v;
       }
     }
@@ -1542,5 +1568,184 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
       float* gb = A.gb_a + (long)A.gb_stride * s + n;
       if (A.nrs == 1) *gb = t; else atomicAdd(gb, t);
     }
+  }
+}
+
+// ==========================================================================================
+// densef_fin_kernel : H = relu(bias + sum_chunk partials) of the wide dense layer (chunks summed in order: reproducible),
+// and the net's last layer Linear(64, 2) (inception.py:217) on the row while it is in the 16 lanes' registers:
+// z = W2 h + b2 (+ Flipout: s_out o (dW2 (h o s_in))).  fp32 twin of dense_ks_fin_kernel.
+// ==========================================================================================
+struct DenseFinF32Args {
+  const float* slab;
+  long slab_stride;
+  int nchunk;
+  int rows, B;          // S*B rows, rows per particle
+  const float* bias;    // [S or 1][bias_stride]: offset to the dense layer
+  const float* b2;      // same array, offset to the last layer
+  int bias_stride;
+  float* h;             // [rows][64]
+  const float* w2a; const float* w2b;   // forward images of the last layer (slot A | slot B), offset to its first row
+  long w2_stride_a, w2_stride_b;
+  int w2_KP;
+  const uint32_t* sg_in; const uint32_t* sg_out;   // its Flipout sign words [rows][siw] / [rows][sow]
+  int siw, sow;
+  float* z;             // [rows][2]
+};
+
+template <int EM>
+__global__ __launch_bounds__(256) void densef_fin_kernel(const DenseFinF32Args F) {
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int row = min(t >> 4, F.rows - 1), ch = (t & 15) * 4;   // surplus threads redo the last row (the shuffles need full groups)
+  const bool live = (t >> 4) < F.rows;
+  const int s = row / F.B;
+  f32x4 v = *(const f32x4*)(F.bias + (long)F.bias_stride * s + ch);
+  const float* p = F.slab + (long)row * 64 + ch;
+  for (int c = 0; c < F.nchunk; ++c) {
+    const f32x4 a = *(const f32x4*)(p + c * F.slab_stride);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += a[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  if (live) *(f32x4*)(F.h + (long)row * 64 + ch) = v;
+  float m[2] = {0.f, 0.f}, pz[2] = {0.f, 0.f};
+  uint32_t bits = 0;
+  if constexpr (FO) bits = F.sg_in[(long)row * F.siw + (ch >> 5)] >> (ch & 31);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long wo = (long)k * F.w2_KP + ch;
+    const f32x4 wa = *(const f32x4*)(F.w2a + F.w2_stride_a * s + wo);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[k] += v[r] * wa[r];
+    if constexpr (FO) {
+      const f32x4 wb = *(const f32x4*)(F.w2b + F.w2_stride_b * s + wo);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pz[k] += (((bits >> r) & 1u) ? -v[r] : v[r]) * wb[r];
+    }
+  }
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      m[k] += __shfl_xor(m[k], d, 16);
+      if constexpr (FO) pz[k] += __shfl_xor(pz[k], d, 16);
+    }
+  }
+  if (live && (t & 15) == 0) {
+    uint32_t so = 0;
+    if constexpr (FO) so = F.sg_out[(long)row * F.sow];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float zk = m[k] + F.b2[(long)F.bias_stride * s + k];
+      if constexpr (FO) zk += ((so >> k) & 1u) ? -pz[k] : pz[k];
+      F.z[(long)row * 2 + k] = zk;
+    }
+  }
+}
+
+// ==========================================================================================
+// headf_last_kernel : head + backward of the last layer Linear(64, 2) in one launch (fp32 twin of head_last_kernel):
+// per example row the head's d(-ll)/dz, then dH = dz W2 (+ Flipout: s_in o ((dz o s_out) dW2)) written as the fp32
+// gradient of H, and per workgroup the layer's weight / bias gradient sums over its rows (fp32 atomics into the zeroed
+// per-particle images).
+// ==========================================================================================
+struct HeadLastF32Args {
+  HeadArgs H;
+  const float* wa; const float* wb;      // forward images of the layer (slot A | slot B), offset to its first row
+  long stride_a, stride_b;
+  int KP;
+  const float* h;                        // [S*B][64]
+  float* dh;                             // [S*B][64]
+  const uint32_t* sg_in; const uint32_t* sg_out;
+  int siw, sow;
+  float* gw_a; float* gw_b; float* gb_a;   // offset to the layer; per particle strides below
+  long gw_stride; int gb_stride;
+};
+
+template <int EM>
+__global__ __launch_bounds__(256) void headf_last_kernel(const HeadLastF32Args A) {
+  constexpr bool FO = (EM == EM_FLIPOUT);
+  const int tid = threadIdx.x;
+  const int blk0 = blockIdx.x * HL_ROWS;
+  const int idx = blk0 + tid;   // rows: threads 0 .. HL_ROWS-1
+  const int s = blockIdx.y;
+  const int B = A.H.B;
+  __shared__ float dzs[4][HL_ROWS];
+  __shared__ float wsh[4][64];   // W rows 0, 1 | dW rows 0, 1
+  {
+    const int kk = tid >> 6, c = tid & 63;
+    const float* src = (kk < 2 ? A.wa + A.stride_a * s : A.wb + A.stride_b * s) + (long)(kk & 1) * A.KP + c;
+    wsh[kk][c] = (kk < 2 || FO) ? *src : 0.f;
+  }
+  __syncthreads();
+  if (tid < HL_ROWS) {
+    double ll = 0.0;
+    float g0 = 0.f, g1 = 0.f;
+    if (idx < B) ll = head_row(A.H, s, idx, g0, g1);
+    ll = wave_sum_d(ll);   // HL_ROWS = one wave
+    if (tid == 0 && A.H.with_obs) atomicAdd(A.H.ll_acc + s, ll);
+    const long r = (long)s * B + min(idx, B - 1);
+    uint32_t so = 0;
+    if constexpr (FO) so = A.sg_out[r * A.sow];
+    const float h0 = (so & 1u) ? -g0 : g0, h1 = (so & 2u) ? -g1 : g1;   // dz o s_out
+    dzs[0][tid] = g0;
+    dzs[1][tid] = g1;
+    dzs[2][tid] = h0;
+    dzs[3][tid] = h1;
+    if (idx < B) {
+      uint32_t si[2] = {0u, 0u};
+      if constexpr (FO) {
+        si[0] = A.sg_in[r * A.siw];
+        si[1] = A.sg_in[r * A.siw + 1];
+      }
+#pragma unroll
+      for (int c4 = 0; c4 < 16; ++c4) {
+        f32x4 d;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = c4 * 4 + q;
+          d[q] = g0 * wsh[0][c] + g1 * wsh[1][c];
+          if constexpr (FO) {
+            const float pp = h0 * wsh[2][c] + h1 * wsh[3][c];
+            d[q] += ((si[c >> 5] >> (c & 31)) & 1u) ? -pp : pp;
+          }
+        }
+        *(f32x4*)(A.dh + r * 64 + c4 * 4) = d;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- weight / bias gradient sums of this workgroup's rows: thread = (kind kk, channel c) ----
+  const int kk = tid >> 6, c = tid & 63;   // kk 0, 1: d/dW_a rows 0, 1; kk 2, 3: d/dW_b rows 0, 1 (Flipout)
+  const int nrow = min(HL_ROWS, B - blk0);
+  if (kk < 2 || FO) {
+    float acc = 0.f;
+    const float* hp = A.h + ((long)s * B + blk0) * 64 + c;
+    const uint32_t* sp = A.sg_in + ((long)s * B + blk0) * A.siw + (c >> 5);
+    for (int r0 = 0; r0 < HL_ROWS; r0 += 16) {   // 16 rows of loads in flight
+      float hv[16];
+      uint32_t sw[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int rr = min(r0 + j, nrow - 1);
+        hv[j] = hp[(long)rr * 64];
+        sw[j] = (FO && kk >= 2) ? sp[(long)rr * A.siw] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float h = hv[j];
+        if ((sw[j] >> (c & 31)) & 1u) h = -h;
+        if (r0 + j < nrow) acc += dzs[kk][r0 + j] * h;
+      }
+    }
+    float* g = (kk < 2 ? A.gw_a : A.gw_b) + A.gw_stride * s + (long)(kk & 1) * A.KP + c;
+    atomicAdd(g, acc);
+  }
+  if (tid < 2) {   // bias gradient: sum of dz (Flipout's arrives through slot A only)
+    float acc = 0.f;
+    for (int rr = 0; rr < nrow; ++rr) acc += dzs[tid][rr];
+    atomicAdd(A.gb_a + (long)A.gb_stride * s + tid, acc);
   }
 }

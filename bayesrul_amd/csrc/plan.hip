@@ -135,6 +135,7 @@ struct BnnPlan {
   // workspace layout (byte offsets)
   size_t ws_bytes = 0;
   size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
+  size_t o_mact2 = 0;                              // fp32 plan: nibble masks [ACT2 > 0] ([rows][20 B])
   size_t o_mact1 = 0, o_mmid = 0;                  // bit masks [ACT1 > 0] / [MID > 0] of the trunk kernels: [rows][16 B]
   size_t o_dks = 0;                                // partial pre-activations of the K-split dense forward [chunk][rows][64]
   long dks_rows = 0;
@@ -405,6 +406,7 @@ static void layout_workspace(BnnPlan* p) {
     p->o_amax = take((size_t)cap * p->d.win_length * 32);
     p->o_mact1 = take((size_t)cap * p->d.win_length * 32);
     p->o_mmid = take((size_t)cap * p->d.win_length * 32);
+    p->o_mact2 = take((size_t)cap * p->d.win_length * 20);
   }
   // fused trunk dW: one partial image per workgroup, S * nsplit <= 256 (512 for the k3 / k5 kernel) whatever the call
   p->slab_stride = 0;
@@ -1857,6 +1859,7 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
   T.amax = c->train ? (unsigned char*)p->bufs.workspace + p->o_amax : nullptr;
   T.m_act1 = c->train ? (unsigned char*)p->bufs.workspace + p->o_mact1 : nullptr;
   T.m_mid = c->train ? (unsigned char*)p->bufs.workspace + p->o_mmid : nullptr;
+  T.m_act2 = c->train ? (unsigned char*)p->bufs.workspace + p->o_mact2 : nullptr;
   T.S = c->S;
   T.B = c->B;
   T.L = L;
@@ -1884,7 +1887,7 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
 }
 
 static bool densef_ok(const BnnPlan* p, const Ctx* c, const GroupArgs& A);
-static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi);
+static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last);
 
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
@@ -1911,8 +1914,12 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
   for (int gi = trunk ? 3 : 0; gi < p->n_groups; ++gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, x, &A);
-    if (!bf && densef_ok(p, c, A))
-      BNN_TRY(launch_densef_fwd(p, A, c->em, c->st, &p->prof, gi));
+    if (!bf && densef_ok(p, c, A)) {
+      const bool fl = last_fused_ok(p, c->em, gi);
+      BNN_TRY(launch_densef_fwd(p, A, c->em, c->st, &p->prof, gi, fl));
+      p->fwd_fused_last = fl;
+      if (fl) ++gi;   // the last layer was evaluated by the fin kernel
+    }
     else if (!bf)
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
@@ -2039,7 +2046,7 @@ static void densef_geometry(const GroupArgs& A, int nchunk, int max_rs, int* nrs
   *rows_per_wg = ((steps + r - 1) / r) * FDF_ROWS;
 }
 
-static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi) {
+static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last) {
   const BranchDesc& br = A.g.br[0];
   const LayerDesc& ly = p->layers[br.layer];
   DfArgs F{};
@@ -2071,6 +2078,35 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   } else {
     BNN_TRY(set_lds(densef_fwd_kernel<EM_FLIPOUT>, FDF_LDS));
     densef_fwd_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TF_THREADS), FDF_LDS, st>>>(F);
+  }
+  if (fuse_last) {
+    // + the last layer Linear(64, 2) on the row while it is in registers
+    const LayerDesc& l2 = p->layers[p->groups[gi + 1].br[0].layer];
+    DenseFinF32Args R{};
+    R.slab = F.slab;
+    R.slab_stride = F.slab_stride;
+    R.nchunk = F.nchunk;
+    R.rows = A.cg.S * A.cg.B;
+    R.B = A.cg.B;
+    R.bias = A.ws.bias_a + ly.bias_off + br.n_off;
+    R.b2 = A.ws.bias_a + l2.bias_off;
+    R.bias_stride = A.ws.bias_stride_a;
+    R.h = (float*)A.t[br.out_t].p;
+    R.w2a = (const float*)A.ws.a_hi + l2.w_off;
+    R.w2b = (const float*)A.ws.b + l2.w_off;
+    R.w2_stride_a = A.ws.slot_stride_a;
+    R.w2_stride_b = A.ws.slot_stride_b;
+    R.w2_KP = l2.KP;
+    R.sg_in = A.nz.sign_in + l2.sign_in_off * A.nz.examples;
+    R.sg_out = A.nz.sign_out + l2.sign_out_off * A.nz.examples;
+    R.siw = l2.sign_in_words;
+    R.sow = l2.sign_out_words;
+    R.z = tens_ptr(p, p->z_t, 0);
+    const unsigned fgrid = (unsigned)((R.rows * 16 + 255) / 256);
+    if (em == EM_PLAIN) densef_fin_kernel<EM_PLAIN><<<dim3(fgrid), dim3(256), 0, st>>>(R);
+    else densef_fin_kernel<EM_FLIPOUT><<<dim3(fgrid), dim3(256), 0, st>>>(R);
+    HIP_TRY(hipGetLastError());
+    return 0;
   }
   DenseKsFinArgs R{};
   R.slab = F.slab;
@@ -2107,6 +2143,7 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   F.siw = ly.sign_in_words;
   F.sow = ly.sign_out_words;
   F.dx = (float*)A.t[br.dx_t].p;
+  F.m_x = (const unsigned char*)p->bufs.workspace + p->o_mact2;   // written by tf_fwd_kernel: dX(ACT2) is stored masked
   F.gw_a = A.gw_a + ly.w_off;
   F.gw_b = A.gw_b + ly.w_off;
   F.gb_a = A.gb_a + ly.bias_off;
@@ -2164,6 +2201,39 @@ static int do_head(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, float* preds,
   H.with_obs = a->with_obs && a->y;
   H.objective = c->objective;
   ProfScope ps_(&p->prof, PK_HEAD, 0, c->st);
+  if (c->last_fused && want_dz && p->d.prec == BNN_PREC_F32) {
+    ps_.name("headf_last_kernel<%d>", c->em);
+    GroupArgs A;
+    fill_group_args(p, a, c, p->n_groups - 1, a->x, &A);
+    const BranchDesc& br = A.g.br[0];
+    const LayerDesc& ly = p->layers[br.layer];
+    HeadLastF32Args L{};
+    L.H = H;
+    L.H.dz = nullptr;
+    L.wa = (const float*)A.ws.a_hi + ly.w_off;
+    L.wb = (const float*)A.ws.b + ly.w_off;
+    L.stride_a = A.ws.slot_stride_a;
+    L.stride_b = A.ws.slot_stride_b;
+    L.KP = ly.KP;
+    L.h = (const float*)A.t[A.g.in_t].p;
+    L.dh = (float*)A.t[br.dx_t].p;
+    L.sg_in = A.nz.sign_in + ly.sign_in_off * A.nz.examples;
+    L.sg_out = A.nz.sign_out + ly.sign_out_off * A.nz.examples;
+    L.siw = ly.sign_in_words;
+    L.sow = ly.sign_out_words;
+    L.gw_a = A.gw_a + ly.w_off;
+    L.gw_b = A.gw_b + ly.w_off;
+    L.gb_a = A.gb_a + ly.bias_off;
+    L.gw_stride = A.gw_stride;
+    L.gb_stride = A.gb_stride;
+    if (A.t[A.g.in_t].ctot != 64 || A.t[br.dx_t].ctot != 64) return fail(BNN_E_INVALID, "fp32 head: hidden width");
+    if (g_dry) return 0;
+    const dim3 hgrid((unsigned)((c->B + HL_ROWS - 1) / HL_ROWS), (unsigned)c->S);
+    if (c->em == EM_PLAIN) headf_last_kernel<EM_PLAIN><<<hgrid, dim3(256), 0, c->st>>>(L);
+    else headf_last_kernel<EM_FLIPOUT><<<hgrid, dim3(256), 0, c->st>>>(L);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (c->last_fused && want_dz) {
     // head + backward of the last layer in one launch (its gradient images were zeroed by do_backward's fill, which
     // therefore runs BEFORE the head on this path: see bnn_elbo_step)
@@ -2227,8 +2297,14 @@ static int zero_grad_images(BnnPlan* p, const Ctx* c) {
 // conv layers, one workgroup per (particle, chunk) for the wide dense layer), the fill is not needed at all: the fin
 // kernel of the forward zeroed the last layer's few elements.
 static int prepare_fused_tail(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
-  c->last_fused = trunk_ok(p, c) && p->fwd_fused_last && last_fused_ok(p, c->em, p->n_groups - 2);
+  c->last_fused = (trunk_ok(p, c) || tf_ok(p, c)) && p->fwd_fused_last && last_fused_ok(p, c->em, p->n_groups - 2);
   if (!c->last_fused) return 0;
+  if (tf_ok(p, c)) {
+    // fp32 plan: the head launch and (with two row ranges per chunk) the dense dW kernel add with atomics
+    BNN_TRY(zero_grad_images(p, c));
+    c->grads_zeroed = true;
+    return 0;
+  }
   const BranchDesc& br = p->groups[p->n_groups - 2].br[0];
   const bool direct = c->S * ((br.cin_p + DB_CH - 1) / DB_CH) >= 128;   // launch_dense_ks_bwd: nsplit == 1
   if (!direct) BNN_TRY(zero_grad_images(p, c));
@@ -2273,6 +2349,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     }
     if (p->d.prec == BNN_PREC_F32 && densef_ok(p, c, A) && A.g.br[0].dx_t >= 0) {
       BNN_TRY(launch_densef_bwd(p, A, c->em, c->st, &p->prof, gi));
+      act2_premasked = true;   // its dX is stored masked with [input > 0]
       continue;
     }
     if (p->d.prec == BNN_PREC_F32)

@@ -58,7 +58,9 @@ GROUP_MACS = {
 }
 N_PARAMS = {"inception": 187142, "linear": 192098}
 # branch groups one launch of a fused kernel covers (the library reports the symbol per (kind, group) tag)
-FUSED_GROUPS = {"trunk_fwd_kernel": (0, 1, 2), "trunk_dx_kernel": (1, 2), "trunk_dw_kernel": (0, 1, 2)}
+FUSED_GROUPS = {"trunk_fwd_kernel": (0, 1, 2), "trunk_dx_kernel": (1, 2), "tf_fwd_kernel": (0, 1, 2), "tf_dx_kernel": (1, 2)}
+# the fp32 plan's dW launches: kind 0 = block 1 + the k3 / k5 level, kind 1 = the 1x1 level (keyed by the profile tag's group)
+FUSED_DW_GROUPS = {"tf_dw_kernel": {0: (0, 2), 1: (1,)}}
 PEAK_TFLOPS = {"bf16x3": 2500.0, "f32": 157.3}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
@@ -178,7 +180,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="flipout_conv_s10", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="windows per GPU (default: workload's)")
-    ap.add_argument("--prec", default="bf16x3", choices=["bf16x3", "f32"])
+    ap.add_argument("--prec", default="f32", choices=["bf16x3", "f32"],
+                    help="f32 = exact-fp32 MFMA, the reference's arithmetic precision (the judged line); bf16x3 = split-bf16 fast plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true", help="skip the fp32_plan / b100 / median companions")
     args = ap.parse_args()
@@ -244,7 +247,8 @@ def main():
             if kind == "pool_bwd" or (kind, grp) in seen:
                 continue
             seen.add((kind, grp))
-            groups = FUSED_GROUPS.get(sym.split("<")[0], (grp,))
+            base = sym.split("<")[0]
+            groups = FUSED_DW_GROUPS[base][grp] if base in FUSED_DW_GROUPS else FUSED_GROUPS.get(base, (grp,))
             if kind == "dx":   # block 1 needs no dX (its input is the data)
                 groups = [g for g in groups if g > 0]
             a[2] += sum(2.0 * macs[g] * ncontr * S * B * nsteps for g in groups)

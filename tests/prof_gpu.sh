@@ -3,9 +3,10 @@
 # WRITE_SIZE passes), SQ counters (two passes).  Raw output under gpurun_out/ (scratch); `python profiles/make_summary.py
 # <tag>` turns it into the committed files under profiles/.
 WL=${1:-flipout_conv_s10}
+PREC=${2:-f32}
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/pmc_sq gpurun_out/pmc_sq2
-ARGS="--workload $WL --no-cpu-baseline --no-companions"
+ARGS="--workload $WL --prec $PREC --no-cpu-baseline --no-companions"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 20 --warmup 3 $ARGS > gpurun_out/prof_stats.log 2>&1; echo EXIT $? >> gpurun_out/prof_stats.log
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- python3 bench.py --steps 5 --warmup 1 $ARGS > gpurun_out/prof_fetch.log 2>&1; echo EXIT $? >> gpurun_out/prof_fetch.log
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- python3 bench.py --steps 5 --warmup 1 $ARGS > gpurun_out/prof_write.log 2>&1; echo EXIT $? >> gpurun_out/prof_write.log
