@@ -12,6 +12,11 @@
 //
 // Reference arithmetic: nets/inception.py:10-132 (both inception blocks), [3P] tyxe.poutine.flipout (bayesian.py:68-69).
 #pragma once
+// diagnostics builds only (tests/probes/ablate_gpu.sh): TFV bit 1 = dW without the fold, 2 = forward without epilogue
+// (results wrong); the product library is built with TFV == 0.
+#ifndef TFV
+#define TFV 0
+#endif
 #include "kernels_misc.h"
 #include "kernels_trunk_dw.h"   // kernels_trunk.h (tl_* tables, rot16, lds_barrier) and what kernels_dense_ks.h needs
 #include "kernels_dense_ks.h"   // HL_ROWS, DenseKsFinArgs
@@ -132,50 +137,77 @@ struct TfJobRun {
     constexpr int chb0 = NT * 16;
     // one accumulator per m-tile: out = bias + W_mu x  (+ Flipout: (s_out o dW o s_in) x, both signs folded into the dW fragment)
     f32x4 acc[2] = {bias, bias};
-    uint32_t so = 0;
-    if constexpr (FO) so = (sg[4 + (chb0 >> 5)] >> ((chb0 & 31) + i16)) & 1u;   // s_out of this lane's fragment row (cout)
+    // the window's sign words of this layer, once per job: the per-k-block table index is register arithmetic, the table
+    // read one LDS access (no chain of dependent LDS reads in front of a k-block's MFMAs)
+    uint32_t sw[4] = {0u, 0u, 0u, 0u}, so = 0;
+    if constexpr (FO) {
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
+      for (int w = 0; w < tf_cimg(LY) / 32; ++w) sw[w] = sg[w];
+      so = ((sg[4 + (chb0 >> 5)] >> ((chb0 & 31) + i16)) & 1u) << 4;   // s_out of this lane's fragment row (cout)
+    }
+    // hipcc sinks every LDS read next to its first use (read, wait, 4 MFMAs, read, wait, ...): the operands of k-block
+    // kb + 1 are fetched explicitly BEFORE the MFMAs of k-block kb, scheduling barriers keep the two groups apart
+    struct Op {
+      f32x4 x[2];
+      uint4 m;
+      float xt[2];
+    };
+    auto fetch = [&](int kb, Op& o) __attribute__((always_inline)) {
+      const int tap = kb / CB, cb = kb - tap * CB;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        const int kb = tap * CB + cb;
-        f32x4 x[2];
+      for (int mt = 0; mt < 2; ++mt) o.x[mt] = *(const f32x4*)(lb + (mt * 16 + tap - PAD + HALO) * RS + (tf_inch(LY) + cb * 16) * 4);
+      if constexpr (FO) {
+        // s_in of the layer's own input channels cb*16 + 4 g4 .. + 3
+        const uint32_t nib = (sw[(cb * 16) >> 5] >> (((cb * 16) & 31) + 4 * g4)) & 15u;
+        o.m = lut[so | nib];
+      }
+      if constexpr (TAIL) {
+        if (cb == CB - 1) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) x[mt] = *(const f32x4*)(lb + (mt * 16 + tap - PAD + HALO) * RS + (tf_inch(LY) + cb * 16) * 4);
-        f32x4 wbm = wa[kb];
-        if constexpr (FO) {
-          // s_in of the layer's own input channels cb*16 + 4 g4 .. + 3
-          const uint32_t nib = (sg[(cb * 16) >> 5] >> (((cb * 16) & 31) + 4 * g4)) & 15u;
-          wbm = xor4(wb[kb], lut[(so << 4) | nib]);
+          for (int mt = 0; mt < 2; ++mt) o.xt[mt] = *(const float*)(lr + (mt * 16 + tap - PAD + HALO) * RS + (16 + g4) * 4);
         }
-        // consecutive MFMAs alternate between the two accumulators (dependent issue distance 64 cycles > 40 latency)
+      }
+    };
+    Op cur, nxt;
+    fetch(0, cur);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const int tap = kb / CB, cb = kb - tap * CB;
+      if (kb + 1 < NKB) fetch(kb + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      // consecutive MFMAs alternate between the two accumulators (dependent issue distance 64 cycles > 40 latency)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wa[kb][j], cur.x[mt][j], acc[mt]);
+      if constexpr (FO) {
+        const f32x4 wbm = xor4(wb[kb], cur.m);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wa[kb][j], x[mt][j], acc[mt]);
-        if constexpr (FO) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wbm[j], x[mt][j], acc[mt]);
-        }
+          for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wbm[j], cur.x[mt][j], acc[mt]);
       }
       if constexpr (TAIL) {
-        float xt[2];
+        if (cb == CB - 1) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) xt[mt] = *(const float*)(lr + (mt * 16 + tap - PAD + HALO) * RS + (16 + g4) * 4);
+          for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(ta[tap], cur.xt[mt], acc[mt]);
+          if constexpr (FO) {
+            const uint32_t m = (((sw[0] >> (16 + g4)) & 1u) ^ (so >> 4)) << 31;
+            const float tbm = xor1(tb[tap], m);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(ta[tap], xt[mt], acc[mt]);
-        if constexpr (FO) {
-          const uint32_t m = (((sg[0] >> (16 + g4)) & 1u) ^ so) << 31;
-          const float tbm = xor1(tb[tap], m);
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(tbm, xt[mt], acc[mt]);
+            for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(tbm, cur.xt[mt], acc[mt]);
+          }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- epilogue: ReLU (every conv of the trunk is followed by one: inception.py:48-60, 118-131) ----------------
+    if constexpr (TFV & 2) {
+      asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
+      return;
+    }
     const int chb = chb0 + 4 * g4;
     f32x4 v[2];
 #pragma unroll
@@ -510,22 +542,31 @@ struct TdJobA {
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const char* lb = sl + i16 * TD_RS2 + (CH0 + 4 * g4) * 4;
+    // operands of tap tf + 1 are fetched before the MFMAs of tap tf (see TfJobRun::run)
+    f32x4 xc[2], xn[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) xc[mt] = *(const f32x4*)(lb + (mt * 16 - PAD + HALO) * TD_RS2);
 #pragma unroll
     for (int tf = 0; tf < TAPS; ++tf) {
-      f32x4 x[2];
+      if (tf + 1 < TAPS) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) x[mt] = *(const f32x4*)(lb + (mt * 16 + tf - PAD + HALO) * TD_RS2);
+        for (int mt = 0; mt < 2; ++mt) xn[mt] = *(const f32x4*)(lb + (mt * 16 + tf + 1 - PAD + HALO) * TD_RS2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wa[tf][j], x[mt][j], acc[mt]);
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wa[tf][j], xc[mt][j], acc[mt]);
       if constexpr (FO) {
         const f32x4 wbm = xor4(wb[tf], fm);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wbm[j], x[mt][j], acc[mt]);
+          for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wbm[j], xc[mt][j], acc[mt]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      xc[0] = xn[0];
+      xc[1] = xn[1];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -578,41 +619,62 @@ struct TdJobB {
     f32x4 accp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const char* b2 = sl + (i16 + HALO) * TD_RS2 + g4 * 16;
     const char* bm = dzm + (i16 + HALO) * TF_RSB + g4 * 16;
+    // sign words of the four layers once per job (registers): s_in bit of this lane's fragment row, s_out words
+    uint32_t sib[4] = {0u, 0u, 0u, 0u}, sow[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+    if constexpr (FO) {
+      constexpr int lys[4] = {4, 5, 7, 9};
 #pragma unroll
-    for (int q = 0; q < 11; ++q) {
+      for (int u = 0; u < 4; ++u) {
+        sib[u] = ((sg[lys[u] * 8 + (ci >> 5)] >> (ci & 31)) & 1u) << 4;
+        sow[u][0] = sg[lys[u] * 8 + 4];
+        sow[u][1] = sg[lys[u] * 8 + 5];
+      }
+    }
+    struct Op {
       f32x4 x[2];
+      uint4 m;
+    };
+    auto fetch = [&](int q, Op& o) __attribute__((always_inline)) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const char* bp;
         if (q == 0) bp = b2 + mt * 16 * TD_RS2;
         else if (q >= 9) bp = b2 + mt * 16 * TD_RS2 + (48 + (q - 9) * 16) * 4;
         else bp = bm + mt * 16 * TF_RSB + (q - 1) * 64;
-        x[mt] = *(const f32x4*)bp;
+        o.x[mt] = *(const f32x4*)bp;
       }
-      f32x4 wbm = wa[q];
       if constexpr (FO) {
-        const int ly = q_layer(q);
-        const uint32_t si = (sg[ly * 8 + (ci >> 5)] >> (ci & 31)) & 1u;
+        const int u = q == 0 ? 0 : (q < 5 ? 1 : (q < 9 ? 2 : 3));
         const int bit = q_kb(q) * 16;
-        const uint32_t nib = (sg[ly * 8 + 4 + (bit >> 5)] >> ((bit & 31) + 4 * g4)) & 15u;
-        wbm = xor4(wb[q], lut[(si << 4) | nib]);
+        const uint32_t nib = (sow[u][bit >> 5] >> ((bit & 31) + 4 * g4)) & 15u;
+        o.m = lut[sib[u] | nib];
       }
+    };
+    Op cur, nxt;
+    fetch(0, cur);
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+      if (q + 1 < 11) fetch(q + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           f32x4& ta = q >= 9 ? accp[mt] : acc[mt];
-          ta = mfma4(wa[q][j], x[mt][j], ta);
+          ta = mfma4(wa[q][j], cur.x[mt][j], ta);
         }
       if constexpr (FO) {
+        const f32x4 wbm = xor4(wb[q], cur.m);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
             f32x4& ta = q >= 9 ? accp[mt] : acc[mt];
-            ta = mfma4(wbm[j], x[mt][j], ta);
+            ta = mfma4(wbm[j], cur.x[mt][j], ta);
           }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
     __builtin_amdgcn_sched_barrier(0);
     // pooled branch: this row's gradient goes to row + code - 1 (codes of the forward's MaxPool1d(3,1,1))
@@ -809,14 +871,13 @@ __global__ __launch_bounds__(TF_THREADS) void tf_dx_kernel(const TfDxArgs A) {
 // product is  (dz o s_out)^T (x o s_in) = (s_in (x) s_out) o (dz^T x):  ONE contraction T per tile and window,
 // acc_mean += T, acc_dW += signs o T (8 VALU instructions instead of 8 MFMAs).
 // Layer 9's operand MaxPool1d(3,1,1)(ACT1) is the maximum of three row-shifted reads of the ACT1 image (ACT1 >= 0, the
-// zero halo rows are the pool's identity).  All 8 waves stage a share of the next window (registers, one step ahead).
+// zero halo rows are the pool's identity).  All 8 waves issue a share of the next window's LDS-DMA instructions (TwDma).
 // ==========================================================================================
 enum {
   TFW_RX = 192, TFW_RB = 576, TFW_RZA = 192, TFW_RZB = 320,
   TFW0_O_X = 0, TFW0_O_XP = TFW0_O_X + IMG_ROWS * TFW_RX, TFW0_O_DZ1 = TFW0_O_XP + IMG_ROWS * TFW_RX,
   TFW0_O_MID = TFW0_O_DZ1 + TILE_ROWS * TFW_RB, TFW0_O_DZ2 = TFW0_O_MID + IMG_ROWS * TFW_RB, TFW0_SLOT = TFW0_O_DZ2 + TILE_ROWS * TFW_RZA,
-  TFW1_O_A1 = 0, TFW1_O_DZM = TFW1_O_A1 + IMG_ROWS * TFW_RB, TFW1_O_DZ2 = TFW1_O_DZM + TILE_ROWS * TFW_RB, TFW1_SLOT = TFW1_O_DZ2 + TILE_ROWS * TFW_RZB,
-  TFW_NLD = 5   // 16-byte chunks per thread and window
+  TFW1_O_A1 = 0, TFW1_O_DZM = TFW1_O_A1 + IMG_ROWS * TFW_RB, TFW1_O_DZ2 = TFW1_O_DZM + TILE_ROWS * TFW_RB, TFW1_SLOT = TFW1_O_DZ2 + TILE_ROWS * TFW_RZB
 };
 template <int KIND> __host__ __device__ constexpr int tw_slot() { return KIND == 0 ? TFW0_SLOT : TFW1_SLOT; }
 template <int KIND> __host__ __device__ constexpr int tw_lds() { return 2 * tw_slot<KIND>() + 2 * 80 * 4; }
@@ -875,16 +936,22 @@ struct TwJob {
     }
   }
 
-  __device__ __forceinline__ void fold(int tt, f32x4 T, const uint32_t* sg, uint32_t sob, int lane) {
-    acc_a[tt] += T;
+  // acc_mean += T, acc_dW += (s_in (x) s_out) o T.  siw = the window's s_in words of this layer (registers), sobx = 15 where
+  // this lane's cout has s_out = -1, else 0.  The sign masks are computed first: they do not depend on T, whose last MFMA
+  // is still in flight when the fold starts (it rides in the shadow of the NEXT tile's MFMAs).
+  __device__ __forceinline__ void fold(int tt, f32x4 T, const uint32_t (&siw)[4], uint32_t sobx, int lane) {
     if constexpr (FO) {
       const int g4 = lane >> 4;
       const int c = tt % NCT;
       const int cbit = (CT0 + c) * 16;   // the layer's own input channel of row 0 of the tile
-      const uint32_t nib = (sg[LY * 8 + (cbit >> 5)] >> ((cbit & 31) + 4 * g4)) & 15u;
+      const uint32_t nibx = ((siw[cbit >> 5] >> ((cbit & 31) + 4 * g4)) & 15u) ^ sobx;
+      uint32_t m[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc_b[tt][r] += xor1(T[r], (((nib >> r) & 1u) ^ sob) << 31);
+      for (int r = 0; r < 4; ++r) m[r] = (nibx >> r) << 31;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc_b[tt][r] += xor1(T[r], m[r]);
     }
+    acc_a[tt] += T;
   }
 
   __device__ __forceinline__ void run(const char* sl, const uint32_t* sg, int lane) {
@@ -895,27 +962,43 @@ struct TwJob {
     float bz[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) bz[ks] = *(const float*)(zi + 4 * ks * tw_zpitch<KIND>(LY));
+    // the window's sign words of this layer, once per job (registers: no LDS read inside the MFMA stream)
+    uint32_t siw[4] = {0u, 0u, 0u, 0u}, sobx = 0;
+    if constexpr (FO) {
+#pragma unroll
+      for (int w = 0; w < tf_cimg(LY) / 32; ++w) siw[w] = sg[LY * 8 + w];
+      sobx = ((sg[LY * 8 + 4 + ((NT * 16) >> 5)] >> (((NT * 16) & 31) + i16)) & 1u) ? 15u : 0u;   // s_out of this lane's column (cout)
+    }
     if constexpr (BIAS) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) bsum += bz[ks];
     }
-    uint32_t sob = 0;
-    if constexpr (FO) sob = (sg[LY * 8 + 4 + ((NT * 16) >> 5)] >> (((NT * 16) & 31) + i16)) & 1u;   // s_out of this lane's column (cout)
+    // Software pipeline inside the wave: the column reads of tile t + 1 are issued before the MFMAs of tile t, and the
+    // fold (VALU) of tile t - 1 is interleaved with them (1 MFMA : up to 4 VALU) - the two waves of a SIMD run the same job
+    // structure in lockstep, so a fold phase between the MFMA phases would leave the matrix pipe idle in both.
+    float axc[8], axn[8];
+    f32x4 Tp = {0.f, 0.f, 0.f, 0.f};
+    load_a(sl, 0, lane, axc);
 #pragma unroll
-    for (int tt = 0; tt < NTILE; tt += 2) {
-      // two tiles at a time: their MFMA chains interleave (a dependent 16x16x4 pair is 40 cycles apart, an issue slot 32)
-      float ax0[8], ax1[8];
-      load_a(sl, tt, lane, ax0);
-      if (tt + 1 < NTILE) load_a(sl, tt + 1, lane, ax1);
-      f32x4 T0 = {0.f, 0.f, 0.f, 0.f}, T1 = {0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < NTILE; ++tt) {
+      if (tt + 1 < NTILE) load_a(sl, tt + 1, lane, axn);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 T = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        T0 = mfma4(ax0[ks], bz[ks], T0);
-        if (tt + 1 < NTILE) T1 = mfma4(ax1[ks], bz[ks], T1);
+      for (int ks = 0; ks < 8; ++ks) T = mfma4(axc[ks], bz[ks], T);
+      if (tt > 0 && !(TFV & 1)) fold(tt - 1, Tp, siw, sobx, lane);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
       }
-      fold(tt, T0, sg, sob, lane);
-      if (tt + 1 < NTILE) fold(tt + 1, T1, sg, sob, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      Tp = T;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) axc[ks] = axn[ks];
     }
+    if constexpr (TFV & 1) acc_a[0] = Tp;
+    else fold(NTILE - 1, Tp, siw, sobx, lane);
   }
 
   __device__ __forceinline__ void flush(const TfDwArgs& A, int slab, int lane) const {
@@ -948,47 +1031,53 @@ struct TwNone {
   __device__ __forceinline__ void flush(const TfDwArgs&, int, int) const {}
 };
 
-// every thread stages TFW_NLD 16-byte chunks of each window: the streams of a kind are enumerated back to back
+// Staging: LDS-DMA (global_load_lds_dwordx4: no data registers, no LDS store instructions).  A DMA instruction writes
+// 64 lanes x 16 B = 1 KB of contiguous LDS, so an image is addressed linearly in 16-byte slots INCLUDING the pad slots of
+// its rows (slot q -> row q / slots_per_row, piece q % slots_per_row; lanes on pad slots or past the last row are masked
+// off).  The instructions of a window are dealt round-robin to the 8 waves (at most TFW_NDMA each); window t + 1 is
+// issued at the start of step t and waited for (vmcnt(0): these waves issue no other VMEM in the loop) before the
+// barrier that ends it.
 struct TwStream {
   const char* base;   // first row of window 0 of this workgroup (+ first byte of the column range)
   int rowbytes;       // global row stride
-  int cpr;            // chunks per row
-  int dstoff, dpitch; // inside a slot
+  int cpr;            // data pieces (16 B) per row
+  int spr;            // LDS slots per row (pitch / 16)
+  int dstoff;         // byte offset of row 0 inside a slot of the ring
 };
+enum { TFW_NDMA = 7 };
 template <bool FO>
-struct TwLoader {
-  const char* src[TFW_NLD];
-  int wstep[TFW_NLD], dst[TFW_NLD];
-  bool on[TFW_NLD];
-  tf_u32x4 d[TFW_NLD];
+struct TwDma {
+  const char* src[TFW_NDMA];
+  int wstep[TFW_NDMA];
+  uint32_t dst[TFW_NDMA];
+  bool on[TFW_NDMA];
   const uint32_t* sg0 = nullptr;
   const uint32_t* sg1 = nullptr;
   long sst0 = 0, sst1 = 0;
-  uint32_t sb0 = 0, sb1 = 0;
-  __device__ __forceinline__ void setup(const TfDwArgs& A, const TwStream* st, int nst, int s, int split, int tid) {
+  __device__ __forceinline__ void setup(const TfDwArgs& A, const TwStream* st, int nst, int s, int split, int wave, int lane) {
     const int L = A.L;
 #pragma unroll
-    for (int j = 0; j < TFW_NLD; ++j) {
-      int q = j * TF_THREADS + tid;
+    for (int j = 0; j < TFW_NDMA; ++j) {
+      int g = j * TF_WAVES + wave;   // instruction index inside the window
       on[j] = false;
       src[j] = st[0].base;
       wstep[j] = 0;
       dst[j] = 0;
       for (int i = 0; i < nst; ++i) {
-        const int n = L * st[i].cpr;
-        if (q >= 0 && q < n) {
-          const int row = q / st[i].cpr, c = q - row * st[i].cpr;
-          on[j] = true;
-          src[j] = st[i].base + (long)row * st[i].rowbytes + c * 16;
+        const int n = L * st[i].spr, ni = (n + 63) >> 6;
+        if (g >= 0 && g < ni) {
+          const int q = g * 64 + lane;
+          const int row = q / st[i].spr, c = q - row * st[i].spr;
+          on[j] = q < n && c < st[i].cpr;
+          src[j] = st[i].base + (on[j] ? (long)row * st[i].rowbytes + c * 16 : 0);
           wstep[j] = A.nsplit * L * st[i].rowbytes;
-          dst[j] = st[i].dstoff + row * st[i].dpitch + c * 16;
+          dst[j] = (uint32_t)(st[i].dstoff + g * 1024);
         }
-        q -= n;
+        g -= ni;
       }
     }
     if constexpr (FO) {
-      if (tid < 64) {
-        const int lane = tid;
+      if (wave == 0) {
         auto one = [&](int layer, int kk, const uint32_t*& q, long& stride) {
           const LayerDesc ly = A.layers[layer];
           if (kk < 4 && kk < ly.sign_in_words) {
@@ -1004,23 +1093,14 @@ struct TwLoader {
       }
     }
   }
-  __device__ __forceinline__ void fetch(int k) {
+  // window k -> ring slot at LDS byte address `slot`, its sign words at `sgw`
+  __device__ __forceinline__ void issue(int k, uint32_t slot, uint32_t sgw) {
 #pragma unroll
-    for (int j = 0; j < TFW_NLD; ++j) d[j] = *(const tf_u32x4*)(src[j] + (long)k * wstep[j]);
+    for (int j = 0; j < TFW_NDMA; ++j)
+      if (on[j]) dma16(src[j] + (long)k * wstep[j], __builtin_amdgcn_readfirstlane(slot + dst[j]));
     if constexpr (FO) {
-      if (sg0) sb0 = sg0[(long)k * sst0];
-      if (sg1) sb1 = sg1[(long)k * sst1];
-    }
-  }
-  __device__ __forceinline__ void put(char* slot, uint32_t* sgw, int tid) {
-#pragma unroll
-    for (int j = 0; j < TFW_NLD; ++j)
-      if (on[j]) *(tf_u32x4*)(slot + dst[j]) = d[j];
-    if constexpr (FO) {
-      if (tid < 64) {
-        sgw[tid] = sb0;
-        if (tid < 16) sgw[64 + tid] = sb1;
-      }
+      if (sg0) dma4(sg0 + (long)k * sst0, __builtin_amdgcn_readfirstlane(sgw));
+      if (sg1) dma4(sg1 + (long)k * sst1, __builtin_amdgcn_readfirstlane(sgw + 256));
     }
   }
 };
@@ -1030,28 +1110,29 @@ __device__ __forceinline__ void tw_role(const TfDwArgs& A, char* smem, const TwS
   constexpr bool FO = (EM == EM_FLIPOUT);
   constexpr int SLOT = tw_slot<KIND>();
   const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   J0 j0;
   J1 j1;
   J2 j2;
   j0.init();
   j1.init();
   j2.init();
-  TwLoader<FO> ld;
-  ld.setup(A, st, nst, s, split, tid);
-  uint32_t* sgb = (uint32_t*)(smem + 2 * SLOT);
-  if (nwin > 0) ld.fetch(0);
+  TwDma<FO> ld;
+  ld.setup(A, st, nst, s, split, wave, lane);
+  const uint32_t lds0 = lds_addr(smem), sgb0 = lds0 + 2 * SLOT;
+  const uint32_t* sgb = (const uint32_t*)(smem + 2 * SLOT);
   __syncthreads();   // zero fill
-  if (nwin > 0) ld.put(smem, sgb, tid);
-  if (nwin > 1) ld.fetch(1);
+  if (nwin > 0) ld.issue(0, lds0, sgb0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
   for (int t = 0; t < nwin; ++t) {
-    if (t + 1 < nwin) ld.put(smem + ((t + 1) & 1) * SLOT, sgb + ((t + 1) & 1) * 80, tid);
-    if (t + 2 < nwin) ld.fetch(t + 2);
+    if (t + 1 < nwin) ld.issue(t + 1, lds0 + ((t + 1) & 1) * SLOT, sgb0 + ((t + 1) & 1) * 320);
     const char* sl = smem + (t & 1) * SLOT;
     const uint32_t* sg = sgb + (t & 1) * 80;
     j0.run(sl, sg, lane);
     j1.run(sl, sg, lane);
     j2.run(sl, sg, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
   }
   j0.flush(A, (int)blockIdx.x, lane);   // slab = this workgroup's (particle, split)
@@ -1075,16 +1156,16 @@ __global__ __launch_bounds__(TF_THREADS) void tf_dw_kernel(const TfDwArgs A) {
   TwStream st[5];
   int nst;
   if constexpr (KIND == 0) {
-    st[0] = TwStream{(const char*)A.xp[0] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFW0_O_X + HALO * TFW_RX, TFW_RX};
-    st[1] = TwStream{(const char*)A.xp[1] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFW0_O_XP + HALO * TFW_RX, TFW_RX};
-    st[2] = TwStream{(const char*)A.g_act1 + pr * 512, 512, 32, TFW0_O_DZ1, TFW_RB};
-    st[3] = TwStream{(const char*)A.mid + pr * 512, 512, 32, TFW0_O_MID + HALO * TFW_RB, TFW_RB};
-    st[4] = TwStream{(const char*)A.g_act2 + pr * 320 + 64, 320, 8, TFW0_O_DZ2, TFW_RZA};
+    st[0] = TwStream{(const char*)A.xp[0] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFW_RX / 16, TFW0_O_X + HALO * TFW_RX};
+    st[1] = TwStream{(const char*)A.xp[1] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFW_RX / 16, TFW0_O_XP + HALO * TFW_RX};
+    st[2] = TwStream{(const char*)A.g_act1 + pr * 512, 512, 32, TFW_RB / 16, TFW0_O_DZ1};
+    st[3] = TwStream{(const char*)A.mid + pr * 512, 512, 32, TFW_RB / 16, TFW0_O_MID + HALO * TFW_RB};
+    st[4] = TwStream{(const char*)A.g_act2 + pr * 320 + 64, 320, 8, TFW_RZA / 16, TFW0_O_DZ2};
     nst = 5;
   } else {
-    st[0] = TwStream{(const char*)A.act1 + pr * 512, 512, 32, TFW1_O_A1 + HALO * TFW_RB, TFW_RB};
-    st[1] = TwStream{(const char*)A.g_mid + pr * 512, 512, 32, TFW1_O_DZM, TFW_RB};
-    st[2] = TwStream{(const char*)A.g_act2 + pr * 320, 320, 20, TFW1_O_DZ2, TFW_RZB};
+    st[0] = TwStream{(const char*)A.act1 + pr * 512, 512, 32, TFW_RB / 16, TFW1_O_A1 + HALO * TFW_RB};
+    st[1] = TwStream{(const char*)A.g_mid + pr * 512, 512, 32, TFW_RB / 16, TFW1_O_DZM};
+    st[2] = TwStream{(const char*)A.g_act2 + pr * 320, 320, 20, TFW_RZB / 16, TFW1_O_DZ2};
     nst = 3;
   }
 #define TWJ(...) TwJob<EM, KIND, __VA_ARGS__>
@@ -1226,20 +1307,42 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
     const uint32_t* sgl = (const uint32_t*)(sl + FDF_O_SG) + (mh * 16 + i16) * FDF_SGW;
     const char* lb = sl + (mh * 16 + i16) * FDF_RSX + g4 * 16;
     f32x4 accm = {0.f, 0.f, 0.f, 0.f}, accp = {0.f, 0.f, 0.f, 0.f};
+    // this row's s_in words of the chunk, once per step (registers); operands of k-block kb + 1 are fetched before the
+    // MFMAs of k-block kb (see TfJobRun::run)
+    uint32_t swr[9];
+    const int hi16 = (ch0 >> 4) & 1;
+    if constexpr (FO) {
+#pragma unroll
+      for (int w = 0; w < 9; ++w) swr[w] = sgl[w];
+    }
+    struct Op {
+      f32x4 x;
+      uint4 m;
+    };
+    auto fetchop = [&](int kb, Op& o) __attribute__((always_inline)) {
+      o.x = *(const f32x4*)(lb + kb * 64);
+      if constexpr (FO) {
+        // image channel of this lane's 4 values: c = ch0 + kb*16 + 4 g4; ch0 = 0 or 16 (mod 32)
+        // (the 16-channel block never straddles a sign word)
+        const uint32_t word = hi16 ? swr[(kb + 1) >> 1] : swr[kb >> 1];
+        o.m = lut[(word >> ((((kb + hi16) & 1) << 4) + 4 * g4)) & 15u];
+      }
+    };
+    Op cur, nxt;
+    fetchop(0, cur);
 #pragma unroll
     for (int kb = 0; kb < FDF_KB; ++kb) {
-      const f32x4 x = *(const f32x4*)(lb + kb * 64);
-      f32x4 xs = x;
-      if constexpr (FO) {
-        const int c = ch0 + kb * 16 + 4 * g4;   // image channel of this lane's 4 values
-        const uint32_t nib = (sgl[(c >> 5) - w0] >> (c & 31)) & 15u;
-        xs = xor4(x, lut[nib]);
-      }
+      if (kb + 1 < FDF_KB) fetchop(kb + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 xs = cur.x;
+      if constexpr (FO) xs = xor4(cur.x, cur.m);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        accm = mfma4(wa[kb][j], x[j], accm);
+        accm = mfma4(wa[kb][j], cur.x[j], accm);
         if constexpr (FO) accp = mfma4(wb[kb][j], xs[j], accp);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
     // next step's rows: written after this step's operand reads were issued, loads of the step after that behind them;
     // the partial-sum stores come last (the staging never waits on a store it has just issued)
@@ -1519,24 +1622,41 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
       for (int ks = 0; ks < 8; ++ks) bsum += bz[ks];
     }
     const uint32_t* sgl = (const uint32_t*)(sl + DWF_O_SG) + g4 * FDF_SGW;
+    // tile m = c-tile cpar + 2 m (tile 7 exists for cpar = 0 only); the column reads (and sign words) of tile m + 1 are
+    // issued before the MFMAs of tile m
+    struct Op {
+      float ax[8];
+      uint32_t sw[FO ? 8 : 1];
+    };
+    auto fetchop = [&](int m, Op& o) __attribute__((always_inline)) {
+      const int ct = min(cpar + 2 * m, FDF_KB - 1);
+      const char* xi = sl + g4 * DWF_RSX + (ct * 16 + i16) * 4;
+      const int c = ch0 + ct * 16 + i16;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        o.ax[ks] = *(const float*)(xi + 4 * ks * DWF_RSX);
+        if constexpr (FO) o.sw[ks] = sgl[4 * ks * FDF_SGW + (c >> 5) - w0];
+      }
+    };
+    Op cur, nxt;
+    fetchop(0, cur);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const int ct = cpar + 2 * m;
-      if (ct < FDF_KB) {
-        const char* xi = sl + g4 * DWF_RSX + (ct * 16 + i16) * 4;
-        const int c = ch0 + ct * 16 + i16;
-        float ax[8];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) ax[ks] = *(const float*)(xi + 4 * ks * DWF_RSX);
+      if (m + 1 < 8) fetchop(m + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      if (m < 7 || cpar == 0) {
+        const int c = ch0 + (cpar + 2 * m) * 16 + i16;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          acc_a[m] = mfma4(ax[ks], bz[ks], acc_a[m]);
+          acc_a[m] = mfma4(cur.ax[ks], bz[ks], acc_a[m]);
           if constexpr (FO) {
-            const uint32_t bit = (sgl[4 * ks * FDF_SGW + (c >> 5) - w0] >> (c & 31)) & 1u;
-            acc_b[m] = mfma4(xor1(ax[ks], bit << 31), bzs[ks], acc_b[m]);
+            const uint32_t bit = (cur.sw[ks] >> (c & 31)) & 1u;
+            acc_b[m] = mfma4(xor1(cur.ax[ks], bit << 31), bzs[ks], acc_b[m]);
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
     lds_barrier();
   }

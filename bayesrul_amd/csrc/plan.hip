@@ -2008,7 +2008,12 @@ static int launch_tf_dw(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int kind
   T.nsplit = tf_nsplit(c);
   BNN_TRY(check_slab_slots(p, c, 0, T.nsplit));
   static_assert(tw_lds<0>() <= 160 * 1024 && tw_lds<1>() <= 160 * 1024, "LDS budgets");
-  if (T.L * 84 > TFW_NLD * TF_THREADS) return fail(BNN_E_INVALID, "fp32 trunk dW: window too long for the staging plan");
+  {
+    // LDS-DMA instructions per window (64 slots of 16 B each, pad slots included) against the 8 x TFW_NDMA the waves issue
+    auto ni = [&](int spr) { return (T.L * spr + 63) / 64; };
+    const int n0 = 3 * ni(TFW_RX / 16) + 2 * ni(TFW_RB / 16), n1 = 2 * ni(TFW_RB / 16) + ni(TFW_RZB / 16);
+    if (std::max(n0, n1) > TFW_NDMA * TF_WAVES) return fail(BNN_E_INVALID, "fp32 trunk dW: window too long for the staging plan");
+  }
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DW, kind == 0 ? 0 : 1, c->st);
   ps_.name("tf_dw_kernel<%d, %d>", c->em, kind);

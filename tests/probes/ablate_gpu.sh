@@ -7,7 +7,7 @@ mkdir -p gpurun_out /tmp/abl
 cd bayesrul_amd/csrc
 for v in base $1; do
   flag=""; [ "$v" != base ] && flag="-D$v"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC $flag -o /tmp/abl/lib_$v.so plan.hip &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ${ABL_CFLAGS--Xclang -target-feature -Xclang -packed-fp32-ops} $flag -o /tmp/abl/lib_$v.so plan.hip &
 done
 wait
 cd ../..
