@@ -12,7 +12,7 @@
 //
 // Reference arithmetic: nets/inception.py:10-132 (both inception blocks), [3P] tyxe.poutine.flipout (bayesian.py:68-69).
 #pragma once
-// diagnostics builds only (tests/probes/ablate_gpu.sh): TFV bit 1 = dW without the fold, 2 = forward without epilogue
+// diagnostics builds only (tests/probes/ablate_gpu.sh): TFV bit 1 = dW without the fold arithmetic, 2 = forward without epilogue, 4 = dW without its DMAs
 // (results wrong); the product library is built with TFV == 0.
 #ifndef TFV
 #define TFV 0
@@ -880,7 +880,9 @@ enum {
   TFW1_O_A1 = 0, TFW1_O_DZM = TFW1_O_A1 + IMG_ROWS * TFW_RB, TFW1_O_DZ2 = TFW1_O_DZM + TILE_ROWS * TFW_RB, TFW1_SLOT = TFW1_O_DZ2 + TILE_ROWS * TFW_RZB
 };
 template <int KIND> __host__ __device__ constexpr int tw_slot() { return KIND == 0 ? TFW0_SLOT : TFW1_SLOT; }
-template <int KIND> __host__ __device__ constexpr int tw_lds() { return 2 * tw_slot<KIND>() + 2 * 80 * 4; }
+// ring of window slots: the 1x1 kind fits three (its DMAs run two steps ahead), the other kind two
+template <int KIND> __host__ __device__ constexpr int tw_nslot() { return KIND == 0 ? 2 : 3; }
+template <int KIND> __host__ __device__ constexpr int tw_lds() { return tw_nslot<KIND>() * (tw_slot<KIND>() + 80 * 4); }
 
 struct TfDwArgs {
   const float* xp[2];      // [B*L][20] x, pooled x
@@ -940,6 +942,10 @@ struct TwJob {
   // this lane's cout has s_out = -1, else 0.  The sign masks are computed first: they do not depend on T, whose last MFMA
   // is still in flight when the fold starts (it rides in the shadow of the NEXT tile's MFMAs).
   __device__ __forceinline__ void fold(int tt, f32x4 T, const uint32_t (&siw)[4], uint32_t sobx, int lane) {
+    if constexpr (TFV & 1) {   // diagnostics: no fold arithmetic, every tile's MFMAs stay live
+      acc_a[tt] = T;
+      return;
+    }
     if constexpr (FO) {
       const int g4 = lane >> 4;
       const int c = tt % NCT;
@@ -986,7 +992,7 @@ struct TwJob {
       f32x4 T = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) T = mfma4(axc[ks], bz[ks], T);
-      if (tt > 0 && !(TFV & 1)) fold(tt - 1, Tp, siw, sobx, lane);
+      if (tt > 0) fold(tt - 1, Tp, siw, sobx, lane);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -997,8 +1003,7 @@ struct TwJob {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) axc[ks] = axn[ks];
     }
-    if constexpr (TFV & 1) acc_a[0] = Tp;
-    else fold(NTILE - 1, Tp, siw, sobx, lane);
+    fold(NTILE - 1, Tp, siw, sobx, lane);
   }
 
   __device__ __forceinline__ void flush(const TfDwArgs& A, int slab, int lane) const {
@@ -1093,6 +1098,14 @@ struct TwDma {
       }
     }
   }
+  // DMA instructions this wave issues per window (wave-uniform): the counted wait of the ring
+  __device__ __forceinline__ int count() const {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < TFW_NDMA; ++j) n += __builtin_amdgcn_ballot_w64(on[j]) != 0 ? 1 : 0;
+    if constexpr (FO) n += (__builtin_amdgcn_ballot_w64(sg0 != nullptr) != 0 ? 1 : 0) + (__builtin_amdgcn_ballot_w64(sg1 != nullptr) != 0 ? 1 : 0);
+    return n;
+  }
   // window k -> ring slot at LDS byte address `slot`, its sign words at `sgw`
   __device__ __forceinline__ void issue(int k, uint32_t slot, uint32_t sgw) {
 #pragma unroll
@@ -1119,20 +1132,28 @@ __device__ __forceinline__ void tw_role(const TfDwArgs& A, char* smem, const TwS
   j2.init();
   TwDma<FO> ld;
   ld.setup(A, st, nst, s, split, wave, lane);
-  const uint32_t lds0 = lds_addr(smem), sgb0 = lds0 + 2 * SLOT;
-  const uint32_t* sgb = (const uint32_t*)(smem + 2 * SLOT);
+  constexpr int NS = tw_nslot<KIND>(), AHEAD = NS - 1;
+  const int nper = ld.count();
+  const uint32_t lds0 = lds_addr(smem), sgb0 = lds0 + NS * SLOT;
+  const uint32_t* sgb = (const uint32_t*)(smem + NS * SLOT);
   __syncthreads();   // zero fill
-  if (nwin > 0) ld.issue(0, lds0, sgb0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int k = 0; k < AHEAD; ++k)
+    if (k < nwin) ld.issue(k, lds0 + k * SLOT, sgb0 + k * 320);
+  // window 0 landed: everything but the DMAs of the windows issued after it
+  if (AHEAD == 2 && 1 < nwin) BNN_WAIT_VMCNT_WIDE(nper);
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
   for (int t = 0; t < nwin; ++t) {
-    if (t + 1 < nwin) ld.issue(t + 1, lds0 + ((t + 1) & 1) * SLOT, sgb0 + ((t + 1) & 1) * 320);
-    const char* sl = smem + (t & 1) * SLOT;
-    const uint32_t* sg = sgb + (t & 1) * 80;
+    const int ka = t + AHEAD;
+    if (ka < nwin && !(TFV & 4)) ld.issue(ka, lds0 + (ka % NS) * SLOT, sgb0 + (ka % NS) * 320);
+    const char* sl = smem + (t % NS) * SLOT;
+    const uint32_t* sg = sgb + (t % NS) * 80;
     j0.run(sl, sg, lane);
     j1.run(sl, sg, lane);
     j2.run(sl, sg, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // window t + 1 must have landed before the barrier: only the DMAs of later windows may stay in flight
+    if (AHEAD == 2 && t + 2 < nwin) BNN_WAIT_VMCNT_WIDE(nper);
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
   }
   j0.flush(A, (int)blockIdx.x, lane);   // slab = this workgroup's (particle, split)
@@ -1381,6 +1402,7 @@ struct DfBwdArgs {
   float* dx;                            // [S*B][x_ctot]
   const unsigned char* m_x;             // [S*B][x_ctot / 4] nibble masks [X > 0] of the layer's input (null: dX is stored unmasked)
   float* gw_a; float* gw_b; float* gb_a;   // per-particle gradient images of the layer (forward layout [64][KP]) / bias gradients
+  float* gw2_a; float* gw2_b; float* gb2_a;   // the second row range's partial images (same strides; summed by dense_add2_kernel)
   long gw_stride; int gb_stride;
   int KP;
   int S, B, nchunk, nrs, rows_per_wg;
@@ -1660,35 +1682,39 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
     }
     lds_barrier();
   }
-  // ---- flush: transposed tiles (rows = input channels, columns = couts) into the particle's gradient image ----
+  // ---- flush: transposed tiles (rows = input channels, columns = couts), plain stores.  Row range 0 writes the particle's
+  // gradient image, range 1 (if any) a second image that dense_add2_kernel adds afterwards: float atomics from 200
+  // workgroups onto the same 12 MB cost more than the kernel's MFMAs ----
   const int n = nt * 16 + i16;
-  float* gwa = A.gw_a + A.gw_stride * s + (long)n * A.KP + ch0 + 4 * g4;
-  float* gwb = A.gw_b + A.gw_stride * s + (long)n * A.KP + ch0 + 4 * g4;
+  float* gwa = (rs == 0 ? A.gw_a : A.gw2_a) + A.gw_stride * s + (long)n * A.KP + ch0 + 4 * g4;
+  float* gwb = (rs == 0 ? A.gw_b : A.gw2_b) + A.gw_stride * s + (long)n * A.KP + ch0 + 4 * g4;
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const int ct = cpar + 2 * m;
     if (ct < FDF_KB) {
-      if (A.nrs == 1) {
-        *(f32x4*)(gwa + ct * 16) = acc_a[m];
-        if constexpr (FO) *(f32x4*)(gwb + ct * 16) = acc_b[m];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(gwa + ct * 16 + r, acc_a[m][r]);
-          if constexpr (FO) atomicAdd(gwb + ct * 16 + r, acc_b[m][r]);
-        }
-      }
+      *(f32x4*)(gwa + ct * 16) = acc_a[m];
+      if constexpr (FO) *(f32x4*)(gwb + ct * 16) = acc_b[m];
     }
   }
   if (chunk == 0 && cpar == 0) {
     float t = bsum;
     t += __shfl_xor(t, 16, 64);
     t += __shfl_xor(t, 32, 64);
-    if (g4 == 0) {
-      float* gb = A.gb_a + (long)A.gb_stride * s + n;
-      if (A.nrs == 1) *gb = t; else atomicAdd(gb, t);
-    }
+    if (g4 == 0) (rs == 0 ? A.gb_a : A.gb2_a)[(long)A.gb_stride * s + n] = t;
   }
+}
+
+// dst[s][0 .. n) += src[s][0 .. n) over S particles (strides in floats); 4 floats per thread
+__global__ void dense_add2_kernel(float* dst, const float* src, long n, long stride, int S) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int s = blockIdx.y;
+  if (i >= n || s >= S) return;
+  f32x4* d = (f32x4*)(dst + stride * s + i);
+  const f32x4 a = *(const f32x4*)(src + stride * s + i);
+  f32x4 v = *d;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] += a[r];
+  *d = v;
 }
 
 // ==========================================================================================

@@ -135,6 +135,7 @@ struct BnnPlan {
   // workspace layout (byte offsets)
   size_t ws_bytes = 0;
   size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
+  size_t o_dw2_a = 0, o_dw2_b = 0, o_dw2_ba = 0;   // fp32 plan: second partial images of the wide dense layer's dW
   size_t o_mact2 = 0;                              // fp32 plan: nibble masks [ACT2 > 0] ([rows][20 B])
   size_t o_mact1 = 0, o_mmid = 0;                  // bit masks [ACT1 > 0] / [MID > 0] of the trunk kernels: [rows][16 B]
   size_t o_dks = 0;                                // partial pre-activations of the K-split dense forward [chunk][rows][64]
@@ -432,6 +433,11 @@ static void layout_workspace(BnnPlan* p) {
     p->o_mlp_dz4 = take((size_t)cap * 8 * 2 * 2);
   }
   if (p->d.prec == BNN_PREC_F32 && p->d.net == BNN_NET_INCEPTION && p->layers[10].cin % FDF_CH == 0) {
+    // second-row-range partial images of densef_dw_kernel: the dense layer's part of slot A | slot B, and its biases
+    // (laid out like the gradient images themselves: same offsets and particle strides)
+    p->o_dw2_a = take((size_t)S * p->img_total * 4);
+    p->o_dw2_b = take((size_t)S * p->img_total * 4);
+    p->o_dw2_ba = take((size_t)S * p->bias_total * 4);
     p->dks_rows = cap;
     p->o_dks = take((size_t)(p->layers[10].cin / FDF_CH) * cap * 64 * 4);   // partial pre-activations of densef_fwd_kernel
   }
@@ -618,6 +624,7 @@ struct Ctx {
   bool x_planes_ready = false;   // predictive pass, chunks after the first: the planes of x are already in the workspace
   const float* fuse_x = nullptr; // training step on the trunk path: prepare_noise may generate the planes of these windows in
                                  // the launch that generates the noise (step_inputs_kernel)
+  bool direct_assumed = false;   // grads_zeroed was set WITHOUT a fill: the K-split dense backward must store every element
   bool grads_zeroed = false;     // the gradient images need no fill in do_backward (done earlier, or every element is stored)
   bool last_fused = false;       // Inception trunk path: the last layer Linear(64, 2) runs inside the fin / head kernels
   bool head_fused = false;       // bnn_elbo_step on the fused Linear-net path: the head runs inside the backward's first kernel
@@ -1470,14 +1477,21 @@ static int launch_dense_ks_fwd(BnnPlan* p, const GroupArgs& A0, int em, hipStrea
   return 0;
 }
 
+// window splits per (particle, chunk) of the K-split dense backward: 1 = every gradient element is STORED by exactly one
+// workgroup (no zero fill needed: prepare_fused_tail relies on this very rule), else float atomics onto zeroed images
+static int dense_ks_bwd_nsplit(int S, int cin_p, int per_particle) {
+  const int pairs = S * ((cin_p + DB_CH - 1) / DB_CH);
+  return pairs >= 128 ? 1 : std::min(per_particle, (256 + pairs - 1) / pairs);
+}
+
 // dX + dW of the wide dense layer in one launch (kernels_dense_ks.h)
 static int launch_dense_ks_bwd(BnnPlan* p, const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   const BranchDesc& br = A.g.br[0];
   DenseKsPlan F{};
   F.nchunk = (br.cin_p + DB_CH - 1) / DB_CH;
+  F.nsplit = dense_ks_bwd_nsplit(A.cg.S, br.cin_p, A.cg.per_particle);
   const int pairs = A.cg.S * F.nchunk;
-  F.nsplit = pairs >= 128 ? 1 : std::min(A.cg.per_particle, (256 + pairs - 1) / pairs);
   F.ly = p->layers[br.layer];
   F.mask_x = 1;   // the layer's input (ACT2) is the concatenation of ReLU outputs (inception.py:118-131)
   static_assert(DB_LDS <= 160 * 1024 && DB_WAVES <= 16, "one workgroup per CU");
@@ -2165,6 +2179,10 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
     const unsigned grid = (unsigned)(F.S * F.nchunk * F.nrs);
     ProfScope ps_(pf, PK_DW, gi, st);
     ps_.name("densef_dw_kernel<%d>", em);
+    // the second row range's partial images: laid out like the gradient images (same layer offset and particle strides)
+    F.gw2_a = ws_f(p, p->o_dw2_a) + ly.w_off;
+    F.gw2_b = ws_f(p, p->o_dw2_b) + ly.w_off;
+    F.gb2_a = ws_f(p, p->o_dw2_ba) + ly.bias_off;
     if (!g_dry) {
       if (em == EM_PLAIN) {
         BNN_TRY(set_lds(densef_dw_kernel<EM_PLAIN>, DWF_LDS));
@@ -2172,6 +2190,13 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
       } else {
         BNN_TRY(set_lds(densef_dw_kernel<EM_FLIPOUT>, DWF_LDS));
         densef_dw_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TF_THREADS), DWF_LDS, st>>>(F);
+      }
+      if (F.nrs == 2) {
+        const long n = (long)ly.cout * ly.KP;
+        const dim3 ag((unsigned)((n / 4 + 255) / 256), (unsigned)F.S);
+        dense_add2_kernel<<<ag, dim3(256), 0, st>>>(F.gw_a, F.gw2_a, n, F.gw_stride, F.S);
+        if (em == EM_FLIPOUT) dense_add2_kernel<<<ag, dim3(256), 0, st>>>(F.gw_b, F.gw2_b, n, F.gw_stride, F.S);
+        dense_add2_kernel<<<dim3(1, (unsigned)F.S), dim3(256), 0, st>>>(F.gb_a, F.gb2_a, 64, F.gb_stride, F.S);
       }
     }
   }
@@ -2311,9 +2336,10 @@ static int prepare_fused_tail(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
     return 0;
   }
   const BranchDesc& br = p->groups[p->n_groups - 2].br[0];
-  const bool direct = c->S * ((br.cin_p + DB_CH - 1) / DB_CH) >= 128;   // launch_dense_ks_bwd: nsplit == 1
+  const bool direct = dense_ks_bwd_nsplit(c->S, br.cin_p, (c->B + TILE_ROWS - 1) / TILE_ROWS) == 1;
   if (!direct) BNN_TRY(zero_grad_images(p, c));
   c->grads_zeroed = true;
+  c->direct_assumed = direct;   // do_backward refuses to run if the dense group does not take the K-split backward after all
   return 0;
 }
 
@@ -2352,6 +2378,8 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
       act2_premasked = true;   // its dX is stored masked with [input > 0]
       continue;
     }
+    if (A.g.is_dense && c->direct_assumed && gi == p->n_groups - 2)
+      return fail(BNN_E_INVALID, "internal: the gradient images were left unfilled for the K-split dense backward, which this call does not take");
     if (p->d.prec == BNN_PREC_F32 && densef_ok(p, c, A) && A.g.br[0].dx_t >= 0) {
       BNN_TRY(launch_densef_bwd(p, A, c->em, c->st, &p->prof, gi));
       act2_premasked = true;   // its dX is stored masked with [input > 0]

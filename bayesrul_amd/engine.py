@@ -258,12 +258,13 @@ class SviEngine:
     def step(self, x: torch.Tensor, y: torch.Tensor, particles: int, dataset_size: float, prior_loc: float,
              prior_scale: float, adam: Optional[AdamHyper], noise: Optional[InjectedNoise] = None, seed: int = 0,
              step: Optional[int] = None, want_preds: bool = False, global_batch: int = 0,
-             global_batch_offset: int = 0, keep: bool = False):
+             global_batch_offset: int = 0, keep: bool = True):
         """svi.step (A4).  Returns (loss, kl, loglik) as a 3-element device tensor (no host
         sync) and optionally preds [S,B,2].  With ``adam=None`` the gradient is left in
         ``self.grad`` for the DP all-reduce (see parallel.py) and no update is applied.
-        The result is a VIEW of one of ``RESULT_SLOTS`` ring slots: it stays valid for the next RESULT_SLOTS - 1 steps
-        (read or ``.item()`` it before that; ``keep=True`` returns a private copy at the price of a copy kernel)."""
+        ``keep=True`` (default) returns a private copy of the three scalars; ``keep=False`` returns a VIEW of one of
+        ``RESULT_SLOTS`` ring slots (no copy kernel) that stays valid for the next RESULT_SLOTS - 1 steps only - for
+        callers that read the result at once (bench.py, parallel.dp_step)."""
         with torch.cuda.device(self.device):
             a = self._elbo_args(x, y, particles, dataset_size, prior_loc, prior_scale, None, 1, 1,
                                 global_batch_offset, global_batch)

@@ -73,8 +73,14 @@ class _DetModule(_Base):
         """net(x) with the current weights, on the device kernels: [B, 2]."""
         from ..engine import InjectedNoise
         eng = self._ensure_engine(self._prec, self._max_batch)
-        _, samples = eng.predict(x.contiguous().float(), 1, noise=InjectedNoise(eps_w=self._zero_eps))
-        return samples[0]
+        x = x.contiguous().float()
+        # the reference's test / predict loaders use test_batch_size = 10000 (data/ncmapss/dataset.py:40,126,135): evaluate in
+        # chunks of the engine's batch capacity
+        outs = []
+        for b0 in range(0, x.shape[0], eng.max_batch):
+            _, samples = eng.predict(x[b0:b0 + eng.max_batch].contiguous(), 1, noise=InjectedNoise(eps_w=self._zero_eps))
+            outs.append(samples[0])
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
 
     def configure_optimizers(self):
         return None

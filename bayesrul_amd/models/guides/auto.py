@@ -24,6 +24,10 @@ class RadialNormal(td.Normal):
 
 
 def _prior_std(method: str, weight: torch.Tensor) -> float:
+    """Fan-based prior-relative scale for a string `init_scale` (guides/radial.py:66-72 calls
+    `tyxe.util.calculate_prior_std` [3P]).  PARITY UNPINNED: TyXe is absent and no shipped config or fixture uses a string
+    init_scale; this uses torch's fan convention (fan_out includes the receptive field, a bias has fan_in = numel), which
+    may differ from TyXe's `fan_in_fan_out` for biases and conv weights.  Do not rely on it matching the reference."""
     fan_in = weight[0].numel() if weight.dim() > 1 else weight.numel()
     fan_out = weight.shape[0] * (weight[0, 0].numel() if weight.dim() > 2 else 1) if weight.dim() > 1 else weight.numel()
     if method == "radford":

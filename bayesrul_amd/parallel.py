@@ -40,7 +40,7 @@ def dp_step(engine, x_local, y_local, particles, dataset_size, prior_loc, prior_
     Returns the [loss, kl, loglik] device tensor of the GLOBAL batch (loss, kl) / local (loglik)."""
     B = x_local.shape[0]
     res = engine.step(x_local, y_local, particles, dataset_size, prior_loc, prior_scale, None, seed=seed, step=step,
-                      global_batch=B * world, global_batch_offset=rank * B)
+                      global_batch=B * world, global_batch_offset=rank * B, keep=False)   # cloned below
     scale = allreduce_mean_(engine.grad, world)
     engine.apply_adam(adam, grad_scale=scale)
     out = res.clone()

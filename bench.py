@@ -224,7 +224,7 @@ def main():
                 return eng.predict(x, S, seed=4321, want_samples=False)[0]
             if world > 1:
                 return dp_step(eng, x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, rank, world, seed=4321)
-            return eng.step(x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, seed=4321)
+            return eng.step(x, y, S, N_DATA, 0.0, wl["prior_scale"], hyp, seed=4321, keep=False)   # result read at once: no copy kernel
         return eng, one_step
 
     eng, one_step = make(args.prec, B)

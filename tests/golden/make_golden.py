@@ -151,5 +151,32 @@ def rmsce_and_frequentist(g):
         torch.Tensor.get_device = orig
 
 
+def deepens():
+    """ref_deepens.npz: bayesrul/models/deepens.py (imports unaided) on a synthetic prediction table: 2 methods x 5 models
+    x 40 windows; `deep_ensemble` of one method's models, and the first ensembles `deep_ensemble_gen` draws."""
+    import pandas as pd
+    sys.path.insert(0, REF)
+    from bayesrul.models.deepens import deep_ensemble, deep_ensemble_gen
+    rng = np.random.default_rng(7)
+    n, rows = 40, []
+    labels = rng.uniform(0, 100, n)
+    for method in ("HNN", "MCD"):
+        for k in range(5):
+            rows.append(pd.DataFrame({"method": method, "model": f"{method}_{k:03d}", "labels": labels,
+                                      "preds": labels + rng.normal(0, 5, n), "stds": rng.uniform(1, 9, n)}))
+    df = pd.concat(rows, ignore_index=True)
+    one = deep_ensemble(df.query("method=='HNN'"))
+    gens = list(deep_ensemble_gen(df, ["HNN", "MCD"], 3, 4))
+    out = {"labels": labels, "preds": df.preds.values, "stds": df.stds.values, "one_preds": one.preds.values,
+           "one_stds": one.stds.values, "gen_preds": np.stack([g.preds.values for g in gens]),
+           "gen_stds": np.stack([g.stds.values for g in gens]), "gen_models": np.array([g.model.iloc[0] for g in gens])}
+    np.savez_compressed(os.path.join(HERE, "ref_deepens.npz"), **out)
+    print("deepens", one.stds.values[:3], [g.model.iloc[0] for g in gens])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "deepens":
+        deepens()
+    else:
+        main()
+        deepens()

@@ -101,7 +101,7 @@ class _OracleEngine:
         self.steps_seen = []
 
     def step(self, x, y, particles, dataset_size, prior_loc, prior_scale, adam, seed=0, step=None, global_batch=0,
-             global_batch_offset=0):
+             global_batch_offset=0, keep=True):
         assert adam is None, "dp_step must leave the update to apply_adam (after the all-reduce)"
         lo = global_batch_offset
         loss, aux = self.st.loss_and_grads(x, y, _slice_noise(self.noise, lo, lo + x.shape[0]))

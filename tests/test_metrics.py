@@ -39,3 +39,26 @@ def test_aggregate_predictions_matches_oracle():
     preds = torch.rand(7, 33, 2, generator=g, dtype=torch.float64) + 0.1
     a, b = aggregate_predictions(preds), R.aggregate_predictions(preds)
     assert torch.allclose(a, b, rtol=1e-12)
+
+
+def test_deep_ensemble_matches_reference(golden_dir):
+    """bayesrul/models/deepens.py:9-49 (ref_deepens.npz, generated from the reference's own functions): the moment-matched
+    mixture of one method's models, and the ensembles `deep_ensemble_gen` draws (random.seed(1), same combinations)."""
+    import pandas as pd
+
+    from bayesrul_amd.models.deepens import deep_ensemble, deep_ensemble_gen
+    z = np.load(os.path.join(golden_dir, "ref_deepens.npz"))
+    n, rows, k0 = len(z["labels"]), [], 0
+    for method in ("HNN", "MCD"):
+        for k in range(5):
+            rows.append(pd.DataFrame({"method": method, "model": f"{method}_{k:03d}", "labels": z["labels"],
+                                      "preds": z["preds"][k0:k0 + n], "stds": z["stds"][k0:k0 + n]}))
+            k0 += n
+    df = pd.concat(rows, ignore_index=True)
+    one = deep_ensemble(df.query("method=='HNN'"))
+    np.testing.assert_allclose(one.preds.values, z["one_preds"], rtol=1e-12)
+    np.testing.assert_allclose(one.stds.values, z["one_stds"], rtol=1e-12)
+    gens = list(deep_ensemble_gen(df, ["HNN", "MCD"], 3, 4))
+    assert [g.model.iloc[0] for g in gens] == list(z["gen_models"]) and all((g.method == "DE").all() for g in gens)
+    np.testing.assert_allclose(np.stack([g.preds.values for g in gens]), z["gen_preds"], rtol=1e-12)
+    np.testing.assert_allclose(np.stack([g.stds.values for g in gens]), z["gen_stds"], rtol=1e-12)

@@ -54,3 +54,21 @@ def test_predictive_pass_geometry_and_refusals(lib):
     N.check(lib.bnn_plan_create(C.byref(d), C.byref(p)))
     assert lib.bnn_plan_validate(p, -1, 100, 10000, 0) == -1 and b"32-bit" in lib.bnn_last_error()
     lib.bnn_plan_destroy(p)
+
+
+@pytest.mark.parametrize("prec", [N.PREC_BF16X3, N.PREC_F32])
+def test_more_than_256_particles_keep_their_dw_slabs_apart(lib, prec):
+    """The trunk dW kernels write one partial image per workgroup: S * nsplit of them, nsplit = max(1, min(B, 256 / S)).
+    Round 2 sized the slab regions for a fixed 256 / 256 / 512: S = 300 ran into the next region, S = 600 past the end
+    (ADVICE r02).  They are sized from max_particles now; a call that would still exceed them is refused."""
+    for S, B in ((300, 4), (600, 2)):
+        d = N.PlanDesc(0, N.MODE_FLIPOUT, prec, S, B, 30, 18, 0)
+        p = C.c_void_p()
+        N.check(lib.bnn_plan_create(C.byref(d), C.byref(p)))
+        try:
+            assert lib.bnn_plan_validate(p, -1, S, B, 1) == 0, lib.bnn_last_error()
+            ws = C.c_size_t()
+            N.check(lib.bnn_plan_workspace_bytes(p, C.byref(ws)))
+            assert ws.value > 0
+        finally:
+            lib.bnn_plan_destroy(p)
