@@ -24,6 +24,7 @@ EXPORTS = [
     "bnn_forward", "bnn_head_nll", "bnn_backward", "bnn_grad_finalize", "bnn_clipped_adam",
     "bnn_elbo_step", "bnn_elbo_evaluate", "bnn_predict", "bnn_export_noise", "bnn_profile_enable",
     "bnn_profile_select", "bnn_profile_name", "bnn_profile_read", "bnn_gather_windows", "bnn_det_step", "bnn_plan_validate",
+    "bnn_det_forward",
 ]
 
 
@@ -62,12 +63,18 @@ class ElboOut(C.Structure):
     _fields_ = [("loss", C.c_void_p), ("kl", C.c_void_p), ("loglik", C.c_void_p), ("preds", C.c_void_p)]
 
 
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_double), ("seed", C.c_uint64), ("step", C.c_uint64), ("keep_act1", C.c_void_p),
+                ("keep_act2", C.c_void_p), ("keep_h", C.c_void_p)]
+
+
 class DetArgs(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("batch", C.c_int32), ("objective", C.c_int32)]
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("batch", C.c_int32), ("objective", C.c_int32),
+                ("dropout", C.POINTER(Dropout))]
 
 
-_ABI_STRUCTS = [PlanDesc, Buffers, Noise, ElboArgs, AdamArgs, ElboOut, DetArgs]
-ABI_VERSION = 2
+_ABI_STRUCTS = [PlanDesc, Buffers, Noise, ElboArgs, AdamArgs, ElboOut, DetArgs, Dropout]
+ABI_VERSION = 3
 _lib: Optional[C.CDLL] = None
 
 

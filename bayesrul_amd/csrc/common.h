@@ -24,7 +24,7 @@ __device__ __forceinline__ float bf2f(u16 h) { return __uint_as_float(((uint32_t
 // Philox4x32-10 counter-based generator; one call = 128 random bits = 4 normals.
 // Streams: key = (seed lo, seed hi); counter = (index lo, index hi | particle, kind | layer<<8, step)
 // ------------------------------------------------------------------------------------------
-enum : uint32_t { NK_EPSW = 1, NK_RADIAL_R = 2, NK_LRT = 3, NK_SIGN_IN = 4, NK_SIGN_OUT = 5 };
+enum : uint32_t { NK_EPSW = 1, NK_RADIAL_R = 2, NK_LRT = 3, NK_SIGN_IN = 4, NK_SIGN_OUT = 5, NK_DROPOUT = 6 };
 
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                uint32_t k1) {

@@ -59,8 +59,27 @@ struct TfArgs {
   unsigned char* m_act1;     // [S*B*L][32] ReLU masks [ACT1 > 0], 4 channels per byte (low nibble)
   unsigned char* m_mid;      // [S*B*L][32] [MID > 0]
   unsigned char* m_act2;     // [S*B*L][20] [ACT2 > 0] (the dense layer's dX applies it)
+  // MC-dropout of the frequentist sibling (DROP instantiations only; nets/inception.py:48-52,119-123: nn.Dropout(p / 4) behind
+  // every branch of both blocks): an element is kept with probability 1 - rate and scaled by 1 / (1 - rate)
+  float drop_rate, drop_scale;
+  uint64_t drop_seed;
+  uint32_t drop_step;
+  const float* keep1;        // injected keep masks (1 keep / 0 drop) [B*L][128], [B*L][80]; null: Philox
+  const float* keep2;
   int S, B, L, nsplit;
 };
+
+// keep mask of 4 consecutive channels of one row: injected floats, or one Philox call (4 x 32 uniform bits)
+__device__ __forceinline__ uint32_t drop_keep4(const float* inj, long o, float rate, uint32_t row, uint32_t quad, uint32_t which,
+                                               uint32_t step, uint64_t seed) {
+  if (inj) {
+    const f32x4 k = *(const f32x4*)(inj + o);
+    return (k[0] > 0.5f ? 1u : 0u) | (k[1] > 0.5f ? 2u : 0u) | (k[2] > 0.5f ? 4u : 0u) | (k[3] > 0.5f ? 8u : 0u);
+  }
+  const uint4 u = philox4x32_10(row, quad, NK_DROPOUT | (which << 8), step, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t thr = (uint32_t)fminf(rate * 4294967296.f, 4294967040.f);   // drop iff u < rate * 2^32
+  return (u.x >= thr ? 1u : 0u) | (u.y >= thr ? 2u : 0u) | (u.z >= thr ? 4u : 0u) | (u.w >= thr ? 8u : 0u);
+}
 
 typedef unsigned int tf_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -85,7 +104,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __bui
 //   = 2 per SIMD, up to 256 registers each: the 22 (layer, n-tile) jobs are dealt so that the four SIMDs carry equal MFMA
 //   counts (596 / 608 / 592 / 604 per window with Flipout); wave 6 also stages the next window's x planes and sign words.
 // ==========================================================================================
-template <int EM, bool TRAIN, class J>
+template <int EM, bool TRAIN, class J, bool DROP = false>
 struct TfJobRun {
   static constexpr int LY = J::layer, NT = J::nt;
   static constexpr bool FO = (EM == EM_FLIPOUT);
@@ -216,6 +235,19 @@ struct TfJobRun {
       for (int r = 0; r < 4; ++r) v[mt][r] = fmaxf(acc[mt][r], 0.f);
     const int L = A.L;
     constexpr int OOFF = tl_ooff(LY), OUTK = tl_outk(LY);
+    if constexpr (DROP && OUTK != 1) {
+      // nn.Dropout behind the branch's last ReLU (block outputs only: MID is inside a branch); the pooled copy, the ReLU
+      // masks and every consumer see the dropped values
+      constexpr int CT = OUTK == 0 ? 128 : 80;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const unsigned R = R0 + (unsigned)min(mt * 16 + i16, L - 1);
+        const uint32_t kb = drop_keep4(OUTK == 0 ? A.keep1 : A.keep2, (long)R * CT + OOFF + chb, A.drop_rate, R,
+                                       (uint32_t)((OOFF + chb) >> 2), (uint32_t)OUTK, A.drop_step, A.drop_seed);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[mt][r] = ((kb >> r) & 1u) ? v[mt][r] * A.drop_scale : 0.f;
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int row = mt * 16 + i16;
@@ -281,8 +313,8 @@ struct TfJobRun {
   }
 };
 
-template <int EM, bool TRAIN>
-struct TfJobRun<EM, TRAIN, TNone> {
+template <int EM, bool TRAIN, bool DROP>
+struct TfJobRun<EM, TRAIN, TNone, DROP> {
   __device__ __forceinline__ void init(const TfArgs&, int, int) {}
   __device__ __forceinline__ void run(const TfArgs&, char*, int, unsigned, int) const {}
 };
@@ -359,11 +391,11 @@ __device__ __forceinline__ constexpr int tfj_stage() {
   else return tl_stage(J::layer);
 }
 
-template <int EM, bool TRAIN, bool LOADER, class J0, class J1, class J2>
+template <int EM, bool TRAIN, bool DROP, bool LOADER, class J0, class J1, class J2>
 __device__ __forceinline__ void tf_role(const TfArgs& A, char* smem, int s, int split, int nwin, int lane) {
-  TfJobRun<EM, TRAIN, J0> r0;
-  TfJobRun<EM, TRAIN, J1> r1;
-  TfJobRun<EM, TRAIN, J2> r2;
+  TfJobRun<EM, TRAIN, J0, DROP> r0;
+  TfJobRun<EM, TRAIN, J1, DROP> r1;
+  TfJobRun<EM, TRAIN, J2, DROP> r2;
   r0.init(A, s, lane);
   r1.init(A, s, lane);
   r2.init(A, s, lane);
@@ -402,7 +434,7 @@ __device__ __forceinline__ void tf_role(const TfArgs& A, char* smem, int s, int 
   }
 }
 
-template <int EM, bool TRAIN>
+template <int EM, bool TRAIN, bool DROP = false>
 __global__ __launch_bounds__(TF_THREADS) void tf_fwd_kernel(const TfArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -414,7 +446,7 @@ __global__ __launch_bounds__(TF_THREADS) void tf_fwd_kernel(const TfArgs A) {
     for (int k = tid; k < TF_O_LUT / 4; k += TF_THREADS) z[k] = 0u;
     build_sign_lut_f32((uint4*)(smem + TF_O_LUT), tid);
   }
-#define TF_ROLE(LD, ...) tf_role<EM, TRAIN, LD, __VA_ARGS__>(A, smem, s, split, nwin, lane)
+#define TF_ROLE(LD, ...) tf_role<EM, TRAIN, DROP, LD, __VA_ARGS__>(A, smem, s, split, nwin, lane)
 #define TJ(...) TJob<__VA_ARGS__>
   // MFMAs per window with Flipout (plain: half): wave w and w + 4 share SIMD w
   switch (wave) {
@@ -493,6 +525,7 @@ struct TfDxArgs {
   const uint32_t* sign_in;
   const uint32_t* sign_out;
   long examples;
+  float drop_scale;              // MC-dropout: 1 / (1 - p/4) on dz(ACT1) (its ReLU mask carries the keep mask); else 1
   int S, B, L, nsplit;
 };
 
@@ -703,7 +736,7 @@ struct TdJobB {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int row = mt * 16 + i16;
-      if (row < L) *(f32x4*)((char*)A.g_act1 + ((R0 + (unsigned)row) * 512u + (unsigned)(och * 4))) = mask4(v[mt], mb[mt]);
+      if (row < L) *(f32x4*)((char*)A.g_act1 + ((R0 + (unsigned)row) * 512u + (unsigned)(och * 4))) = mask4(v[mt], mb[mt]) * A.drop_scale;
     }
   }
 };
@@ -1401,6 +1434,7 @@ struct DfBwdArgs {
   int siw, sow;
   float* dx;                            // [S*B][x_ctot]
   const unsigned char* m_x;             // [S*B][x_ctot / 4] nibble masks [X > 0] of the layer's input (null: dX is stored unmasked)
+  float x_scale, h_scale;               // MC-dropout: 1 / (1 - p/4) on dX, 1 / (1 - p) on dz = dH [H > 0]; else 1
   float* gw_a; float* gw_b; float* gb_a;   // per-particle gradient images of the layer (forward layout [64][KP]) / bias gradients
   float* gw2_a; float* gw2_b; float* gb2_a;   // the second row range's partial images (same strides; summed by dense_add2_kernel)
   long gw_stride; int gb_stride;
@@ -1435,11 +1469,11 @@ struct DzStage {
     if constexpr (FO) so = A.sg_out[R * A.sow + (c4 >> 3)];
   }
   template <bool FO>
-  __device__ __forceinline__ void put(char* dz, char* dzs, int pitch, bool live) const {
+  __device__ __forceinline__ void put(char* dz, char* dzs, int pitch, bool live, float hs) const {
     tf_u32x4 d = g;
     const f32x4 yy = __builtin_bit_cast(f32x4, y);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) d[e] = (live && yy[e] > 0.f) ? d[e] : 0u;
+    for (int e = 0; e < 4; ++e) d[e] = (live && yy[e] > 0.f) ? __float_as_uint(__uint_as_float(d[e]) * hs) : 0u;
     *(tf_u32x4*)(dz + row * pitch + c4 * 16) = d;
     if constexpr (FO) {
       const uint32_t nib = (so >> ((c4 & 7) * 4)) & 15u;
@@ -1491,7 +1525,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
   };
   auto put = [&](int t) __attribute__((always_inline)) {
     char* sl = smem + (t % FDF_NSLOT) * FDX_SLOT;
-    zs.put<FO>(sl, sl + FDX_O_DZS, FDX_RSZ, b0 + t * FDF_ROWS + zs.row < b1);
+    zs.put<FO>(sl, sl + FDX_O_DZS, FDX_RSZ, b0 + t * FDF_ROWS + zs.row < b1, A.h_scale);
     if constexpr (FO) {
       if (sq_on) ((uint32_t*)(sl + FDX_O_SG))[sq_row * FDF_SGW + sq_w] = sw;
     }
@@ -1549,7 +1583,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += ps[r];
         }
-        if (A.m_x) v = mask4(v, mxb[m]);   // the layer's input is a ReLU output: its gradient is wanted where it is positive only
+        if (A.m_x) v = mask4(v, mxb[m]) * A.x_scale;   // the layer's input is a ReLU output: its gradient is wanted where it is positive only
         if (b < b1) *(f32x4*)(A.dx + ((long)s * A.B + b) * A.x_ctot + c) = v;
       }
     }
@@ -1617,7 +1651,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
     for (int j = 0; j < 4; ++j)
       if (xq_row[j] >= 0) *(tf_u32x4*)(sl + xq_dst[j]) = xr[j];
     // rows past the end of the range carry dz = 0: their X rows (clamped copies) do not contribute
-    zs.put<FO>(sl + DWF_O_DZ, sl + DWF_O_DZS, DWF_RSZ, b0 + t * FDF_ROWS + zs.row < b1);
+    zs.put<FO>(sl + DWF_O_DZ, sl + DWF_O_DZS, DWF_RSZ, b0 + t * FDF_ROWS + zs.row < b1, A.h_scale);
     if constexpr (FO) {
       if (sq_on) ((uint32_t*)(sl + DWF_O_SG))[sq_row * FDF_SGW + sq_w] = sw;
     }
@@ -1737,6 +1771,11 @@ struct DenseFinF32Args {
   const uint32_t* sg_in; const uint32_t* sg_out;   // its Flipout sign words [rows][siw] / [rows][sow]
   int siw, sow;
   float* z;             // [rows][2]
+  // MC-dropout behind the hidden layer's ReLU (nets/inception.py:205-207: nn.Dropout(p)): rate 0 = off
+  float drop_rate, drop_scale;
+  uint64_t drop_seed;
+  uint32_t drop_step;
+  const float* keep_h;  // injected keep mask [rows][64]; null: Philox
 };
 
 template <int EM>
@@ -1755,6 +1794,11 @@ __global__ __launch_bounds__(256) void densef_fin_kernel(const DenseFinF32Args F
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  if (F.drop_rate > 0.f) {
+    const uint32_t kb = drop_keep4(F.keep_h, (long)row * 64 + ch, F.drop_rate, (uint32_t)row, (uint32_t)(ch >> 2), 3u, F.drop_step, F.drop_seed);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = ((kb >> r) & 1u) ? v[r] * F.drop_scale : 0.f;
+  }
   if (live) *(f32x4*)(F.h + (long)row * 64 + ch) = v;
   float m[2] = {0.f, 0.f}, pz[2] = {0.f, 0.f};
   uint32_t bits = 0;

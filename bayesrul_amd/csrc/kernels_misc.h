@@ -677,14 +677,17 @@ struct AdamArgs {
 __device__ __forceinline__ void adam_update(const AdamArgs& A, long i, float g0) {
   if (i < A.P ? A.freeze_loc : A.freeze_scale) return;
   float* p = i < A.P ? A.mu + i : A.rho + (i - A.P);
-  float g = g0 * A.grad_scale;
+  // explicitly rounded operations (no mul+add contraction left to the optimiser): the update is the same arithmetic whether
+  // it is inlined behind the chain rule (grad_finalize_kernel) or runs from the gradient buffer (clipped_adam_kernel, the DP
+  // path) - test_dp_step_world1_equals_plain_step holds the two bit for bit
+  float g = __fmul_rn(g0, A.grad_scale);
   g = fminf(fmaxf(g, -A.clip), A.clip);
-  if (A.wd != 0.f) g += A.wd * *p;
-  const float m = A.beta1 * A.m[i] + (1.f - A.beta1) * g;
-  const float v = A.beta2 * A.v[i] + (1.f - A.beta2) * g * g;
+  if (A.wd != 0.f) g = __fmaf_rn(A.wd, *p, g);
+  const float m = __fmaf_rn(A.beta1, A.m[i], __fmul_rn(1.f - A.beta1, g));
+  const float v = __fmaf_rn(A.beta2, A.v[i], __fmul_rn(__fmul_rn(1.f - A.beta2, g), g));
   A.m[i] = m;
   A.v[i] = v;
-  *p -= A.step_size * m / (sqrtf(v) + A.eps);
+  *p = __fsub_rn(*p, __fdiv_rn(__fmul_rn(A.step_size, m), __fadd_rn(__fsqrt_rn(v), A.eps)));
 }
 
 __global__ void clipped_adam_kernel(const AdamArgs A) {

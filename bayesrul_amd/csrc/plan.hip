@@ -496,6 +496,7 @@ extern "C" size_t bnn_abi_sizeof(int which) {
     case 4: return sizeof(BnnAdamArgs);
     case 5: return sizeof(BnnElboOut);
     case 6: return sizeof(BnnDetArgs);
+    case 7: return sizeof(BnnDropout);
   }
   return 0;
 }
@@ -624,6 +625,7 @@ struct Ctx {
   bool x_planes_ready = false;   // predictive pass, chunks after the first: the planes of x are already in the workspace
   const float* fuse_x = nullptr; // training step on the trunk path: prepare_noise may generate the planes of these windows in
                                  // the launch that generates the noise (step_inputs_kernel)
+  const BnnDropout* drop = nullptr;   // MC-dropout of this call (frequentist siblings; fp32 Inception plans)
   bool direct_assumed = false;   // grads_zeroed was set WITHOUT a fill: the K-split dense backward must store every element
   bool grads_zeroed = false;     // the gradient images need no fill in do_backward (done earlier, or every element is stored)
   bool last_fused = false;       // Inception trunk path: the last layer Linear(64, 2) runs inside the fin / head kernels
@@ -1830,6 +1832,10 @@ static int launch_trunk_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, bool 
   return 0;
 }
 
+static bool drop_on(const Ctx* c) { return c->drop && c->drop->p > 0.0; }
+// MC-dropout runs on the fused fp32 kernels only: deterministic weights (plain estimator), one particle
+static int check_dropout(const BnnPlan* p, const Ctx* c);
+
 // fused fp32 conv trunk (kernels_f32.h): groups 0..2 of the Inception net in one launch, exact fp32 MFMA
 static bool tf_ok(const BnnPlan* p, const Ctx* c) {
   return p->d.prec == BNN_PREC_F32 && p->d.net == BNN_NET_INCEPTION && c->em != EM_LRT && p->d.win_length <= 30 &&
@@ -1890,7 +1896,21 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
     tf_fwd_kernel<EMV, TRV><<<dim3(grid), dim3(TF_THREADS), TF_LDS, c->st>>>(T);          \
   } while (0)
   BNN_DRY_RETURN();
-  if (c->em == EM_FLIPOUT) {
+  if (drop_on(c)) {
+    T.drop_rate = (float)(c->drop->p / 4);
+    T.drop_scale = (float)(1.0 / (1.0 - c->drop->p / 4));
+    T.drop_seed = c->drop->seed;
+    T.drop_step = (uint32_t)c->drop->step;
+    T.keep1 = c->drop->keep_act1;
+    T.keep2 = c->drop->keep_act2;
+    if (c->train) {
+      BNN_TRY(set_lds((tf_fwd_kernel<EM_PLAIN, true, true>), TF_LDS));
+      tf_fwd_kernel<EM_PLAIN, true, true><<<dim3(grid), dim3(TF_THREADS), TF_LDS, c->st>>>(T);
+    } else {
+      BNN_TRY(set_lds((tf_fwd_kernel<EM_PLAIN, false, true>), TF_LDS));
+      tf_fwd_kernel<EM_PLAIN, false, true><<<dim3(grid), dim3(TF_THREADS), TF_LDS, c->st>>>(T);
+    }
+  } else if (c->em == EM_FLIPOUT) {
     if (c->train) LAUNCH_TF(EM_FLIPOUT, true); else LAUNCH_TF(EM_FLIPOUT, false);
   } else {
     if (c->train) LAUNCH_TF(EM_PLAIN, true); else LAUNCH_TF(EM_PLAIN, false);
@@ -1901,12 +1921,13 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
 }
 
 static bool densef_ok(const BnnPlan* p, const Ctx* c, const GroupArgs& A);
-static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last);
+static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last, const BnnDropout* drop);
 
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
   const bool tf = tf_ok(p, c);
   const bool trunk = trunk_ok(p, c) || tf;
+  BNN_TRY(check_dropout(p, c));
   p->fwd_fused_last = false;
   if (mlp_ok(p, c)) {
     BNN_TRY(launch_mlp_fwd(p, a, c, x));
@@ -1930,7 +1951,7 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
     fill_group_args(p, a, c, gi, x, &A);
     if (!bf && densef_ok(p, c, A)) {
       const bool fl = last_fused_ok(p, c->em, gi);
-      BNN_TRY(launch_densef_fwd(p, A, c->em, c->st, &p->prof, gi, fl));
+      BNN_TRY(launch_densef_fwd(p, A, c->em, c->st, &p->prof, gi, fl, drop_on(c) ? c->drop : nullptr));
       p->fwd_fused_last = fl;
       if (fl) ++gi;   // the last layer was evaluated by the fin kernel
     }
@@ -1979,6 +2000,7 @@ static int launch_tf_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, bool pre
   T.B = c->B;
   T.L = p->d.win_length;
   T.nsplit = tf_nsplit(c);
+  T.drop_scale = drop_on(c) ? (float)(1.0 / (1.0 - c->drop->p / 4)) : 1.f;
   static_assert(TD_LDS <= 160 * 1024, "LDS budget");
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DX, 1, c->st);
@@ -2065,7 +2087,8 @@ static void densef_geometry(const GroupArgs& A, int nchunk, int max_rs, int* nrs
   *rows_per_wg = ((steps + r - 1) / r) * FDF_ROWS;
 }
 
-static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last) {
+static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last, const BnnDropout* drop) {
+  if (drop && !fuse_last) return fail(BNN_E_INVALID, "MC-dropout needs the fused hidden / last layer launch");
   const BranchDesc& br = A.g.br[0];
   const LayerDesc& ly = p->layers[br.layer];
   DfArgs F{};
@@ -2121,6 +2144,13 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
     R.siw = l2.sign_in_words;
     R.sow = l2.sign_out_words;
     R.z = tens_ptr(p, p->z_t, 0);
+    if (drop) {
+      R.drop_rate = (float)drop->p;
+      R.drop_scale = (float)(1.0 / (1.0 - drop->p));
+      R.drop_seed = drop->seed;
+      R.drop_step = (uint32_t)drop->step;
+      R.keep_h = drop->keep_h;
+    }
     const unsigned fgrid = (unsigned)((R.rows * 16 + 255) / 256);
     if (em == EM_PLAIN) densef_fin_kernel<EM_PLAIN><<<dim3(fgrid), dim3(256), 0, st>>>(R);
     else densef_fin_kernel<EM_FLIPOUT><<<dim3(fgrid), dim3(256), 0, st>>>(R);
@@ -2144,7 +2174,7 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   return 0;
 }
 
-static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi) {
+static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, const BnnDropout* drop) {
   const BranchDesc& br = A.g.br[0];
   const LayerDesc& ly = p->layers[br.layer];
   DfBwdArgs F{};
@@ -2163,6 +2193,8 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   F.sow = ly.sign_out_words;
   F.dx = (float*)A.t[br.dx_t].p;
   F.m_x = (const unsigned char*)p->bufs.workspace + p->o_mact2;   // written by tf_fwd_kernel: dX(ACT2) is stored masked
+  F.x_scale = drop ? (float)(1.0 / (1.0 - drop->p / 4)) : 1.f;
+  F.h_scale = drop ? (float)(1.0 / (1.0 - drop->p)) : 1.f;
   F.gw_a = A.gw_a + ly.w_off;
   F.gw_b = A.gw_b + ly.w_off;
   F.gb_a = A.gb_a + ly.bias_off;
@@ -2381,7 +2413,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     if (A.g.is_dense && c->direct_assumed && gi == p->n_groups - 2)
       return fail(BNN_E_INVALID, "internal: the gradient images were left unfilled for the K-split dense backward, which this call does not take");
     if (p->d.prec == BNN_PREC_F32 && densef_ok(p, c, A) && A.g.br[0].dx_t >= 0) {
-      BNN_TRY(launch_densef_bwd(p, A, c->em, c->st, &p->prof, gi));
+      BNN_TRY(launch_densef_bwd(p, A, c->em, c->st, &p->prof, gi, drop_on(c) ? c->drop : nullptr));
       act2_premasked = true;   // its dX is stored masked with [input > 0]
       continue;
     }
@@ -2667,6 +2699,16 @@ extern "C" int bnn_elbo_step(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* n
   return 0;
 }
 
+static int check_dropout(const BnnPlan* p, const Ctx* c) {
+  if (!drop_on(c)) return 0;
+  if (c->drop->p >= 1.0) return fail(BNN_E_INVALID, "dropout rate %g", c->drop->p);
+  if (!tf_ok(p, c) || c->em != EM_PLAIN || c->S != 1 || p->o_dks == 0)
+    return fail(BNN_E_INVALID, "MC-dropout runs on the exact-fp32 Inception plan with deterministic weights (prec f32, one particle)");
+  const int ninj = (c->drop->keep_act1 != nullptr) + (c->drop->keep_act2 != nullptr) + (c->drop->keep_h != nullptr);
+  if (ninj != 0 && ninj != 3) return fail(BNN_E_INVALID, "inject all three dropout keep masks or none");
+  return 0;
+}
+
 // frequentist siblings (frequentist.py:39-48,173-178) on the plain-contraction kernels: weights = mu (zero noise), no KL
 extern "C" int bnn_det_step(BnnPlan* p, const BnnDetArgs* d, const BnnAdamArgs* adam, const BnnElboOut* out, void* stream) {
   if (!p || !d) return fail(BNN_E_INVALID, "null argument");
@@ -2687,6 +2729,7 @@ extern "C" int bnn_det_step(BnnPlan* p, const BnnDetArgs* d, const BnnAdamArgs* 
   Ctx c;
   BNN_TRY(make_ctx(p, &a, nullptr, stream, true, &c));
   c.objective = d->objective;
+  c.drop = d->dropout;
   c.c = (float)(1.0 / d->batch);   // mean over the batch ...
   c.n_over_b = 1.f;
   c.scale_ll = (float)(1.0 / d->batch);
@@ -2708,6 +2751,29 @@ extern "C" int bnn_det_step(BnnPlan* p, const BnnDetArgs* d, const BnnAdamArgs* 
   BNN_TRY(do_loss(p, &a, &c, out, true));
   if (adam) BNN_TRY(do_adam(p, adam, c.st));
   return 0;
+}
+
+extern "C" int bnn_det_forward(BnnPlan* p, const float* x, int32_t batch, const BnnDropout* dropout, float* preds_b2, void* stream) {
+  if (!p || !x || !preds_b2) return fail(BNN_E_INVALID, "null argument");
+  BnnElboArgs a{};
+  a.x = x;
+  a.batch = batch;
+  a.particles = 1;
+  a.global_batch = batch;
+  a.dataset_size = 1.0;
+  a.prior_scale = 1.0;
+  a.mode_override = BNN_MODE_NORMAL;
+  Ctx c;
+  BNN_TRY(make_ctx(p, &a, nullptr, stream, false, &c));
+  c.drop = dropout;
+  float* eps = ws_f(p, p->o_eps);
+  HIP_TRY(hipMemsetAsync(eps, 0, (size_t)p->P * 4, c.st));   // weights = mu
+  BnnNoise nz{};
+  nz.eps_w = eps;
+  BNN_TRY(prepare_noise(p, &a, &nz, &c));
+  BNN_TRY(do_sample(p, &a, &c));
+  BNN_TRY(do_forward(p, &a, &c, x));
+  return do_head(p, &a, &c, preds_b2, false);
 }
 
 extern "C" int bnn_elbo_evaluate(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, const BnnElboOut* out,

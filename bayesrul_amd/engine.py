@@ -280,8 +280,28 @@ class SviEngine:
             res = slot[:3].clone() if keep else slot[:3]
         return (res, preds) if want_preds else res
 
+    def _dropout(self, p: float, seed: int, step: int, keep=None):
+        """BnnDropout of one call: rate p, Philox (seed, step) or injected keep masks (act1 [B*W,128], act2 [B*W,80], h [B,64])."""
+        d = N.Dropout(float(p), int(seed), int(step), 0, 0, 0)
+        if keep is not None:
+            k1, k2, kh = (t.to(self.device, torch.float32).contiguous() for t in keep)
+            d.keep_act1, d.keep_act2, d.keep_h = k1.data_ptr(), k2.data_ptr(), kh.data_ptr()
+            d._keep = (k1, k2, kh)   # keep the buffers alive for the call
+        return d
+
+    def det_forward(self, x: torch.Tensor, dropout: Optional["N.Dropout"] = None) -> torch.Tensor:
+        """net(x) with weights = mu -> [B, 2] (loc, scale); `dropout` (from `_dropout`) keeps nn.Dropout active: one pass of
+        HNN.mc_sampling (frequentist.py:60-81)."""
+        with torch.cuda.device(self.device):
+            assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+            preds = torch.empty(x.shape[0], 2, dtype=torch.float32, device=self.device)
+            N.check(self.lib.bnn_det_forward(self._plan, C.c_void_p(x.data_ptr()), C.c_int32(x.shape[0]),
+                                             C.byref(dropout) if dropout is not None else None,
+                                             C.c_void_p(preds.data_ptr()), C.c_void_p(self._stream())))
+        return preds
+
     def det_step(self, x: torch.Tensor, y: torch.Tensor, objective: str, adam: Optional[AdamHyper],
-                 want_preds: bool = True):
+                 want_preds: bool = True, dropout: Optional["N.Dropout"] = None):
         """One deterministic training step of the net with weights = mu (the frequentist siblings, SURVEY.md 8(f) rank
         4): `objective` = "gaussian_nll" (HNN.step, frequentist.py:39-48) or "mse" (NN.step, :173-178).  Returns the
         mean loss as a 1-element device tensor and the net outputs [B, 2]; d loss / d mu is left in grad[:P]."""
@@ -289,7 +309,7 @@ class SviEngine:
         with torch.cuda.device(self.device):
             assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and y.is_cuda and y.dtype == torch.float32
             B = x.shape[0]
-            d = N.DetArgs(x.data_ptr(), y.data_ptr(), B, obj)
+            d = N.DetArgs(x.data_ptr(), y.data_ptr(), B, obj, C.pointer(dropout) if dropout is not None else None)
             preds = torch.empty(1, B, 2, dtype=torch.float32, device=self.device) if want_preds else None
             out = N.ElboOut(self._scal.data_ptr(), self._scal.data_ptr() + 4, self._scal.data_ptr() + 8, N.ptr(preds))
             ad = self._adam_args(adam, 1.0) if adam is not None else None

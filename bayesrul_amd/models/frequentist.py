@@ -8,7 +8,10 @@ epsilon outside the bias-corrected square root).  Differences, all deliberate:
   * `optimizer` is the Adam argument dict of conf/model/nn.yaml:6-10 (`{lr, weight_decay[, betas, eps]}`) or a
     `functools.partial(torch.optim.Adam, ...)` whose keywords are read — Lightning's automatic optimisation is replaced
     by the fused device optimiser, `configure_optimizers` returns None;
-  * MC-dropout (`p_dropout > 0`, `net.dropout > 0`) is not implemented on the device path and raises;
+  * MC-dropout (`net.dropout > 0`, conf/experiment/ncmapss_mcd.yaml): the keep masks of the nine nn.Dropout modules are
+    drawn inside the kernels from a Philox stream (seed, step counter) instead of torch's generator; the training step
+    runs with dropout active, validation / test / predict run `mc_samples` stochastic passes (`mc_sampling`) as the
+    reference does.  Exact-fp32 plan only (`prec="f32"`);
   * `validation_epoch_end` (Lightning 1.9 API) is kept and also fed by the lite trainer.
 There is no CPU fallback: the step needs the HIP library and a gfx950 device.
 """
@@ -51,8 +54,8 @@ class _DetModule(_Base):
 
     def _ensure_engine(self, prec: str, max_batch: int) -> SviEngine:
         if self.engine is None:
-            if getattr(self.net, "dropout", 0) > 0:
-                raise RuntimeError("MC-dropout is not implemented on the MI355X path (SURVEY.md 8(f))")
+            if getattr(self.net, "dropout", 0) > 0 and (prec != "f32" or self._net_kind() != "inception"):
+                raise RuntimeError("MC-dropout runs on the exact-fp32 Inception kernels: use prec='f32'")
             self.engine = SviEngine(net=self._net_kind(), guide="normal", fit_context=None, prec=prec, max_particles=1,
                                     max_batch=max_batch, win_length=self.net.win_length,
                                     n_features=self.net.n_features, device=self.device)
@@ -69,11 +72,25 @@ class _DetModule(_Base):
                     sd[name].copy_(self.engine.loc(name).to(sd[name].device))
         return self.net
 
-    def forward(self, x):
-        """net(x) with the current weights, on the device kernels: [B, 2]."""
+    # ---- MC-dropout: Philox stream of the keep masks = (seed, a counter that advances with every stochastic pass)
+    _drop_seed, _drop_count = 0x5EED, 0
+
+    def _next_dropout(self, keep=None):
+        """BnnDropout of the next stochastic pass, or None when the net has no dropout."""
+        p = float(getattr(self.net, "dropout", 0) or 0)
+        if p <= 0:
+            return None
+        self._drop_count += 1
+        return self._ensure_engine(self._prec, self._max_batch)._dropout(p, self._drop_seed, self._drop_count, keep)
+
+    def forward(self, x, dropout=None):
+        """net(x) with the current weights, on the device kernels: [B, 2].  `dropout`: a BnnDropout (stochastic pass)."""
         from ..engine import InjectedNoise
         eng = self._ensure_engine(self._prec, self._max_batch)
         x = x.contiguous().float()
+        if dropout is not None:
+            return torch.cat([eng.det_forward(x[b0:b0 + eng.max_batch].contiguous(), dropout)
+                              for b0 in range(0, x.shape[0], eng.max_batch)])
         # the reference's test / predict loaders use test_batch_size = 10000 (data/ncmapss/dataset.py:40,126,135): evaluate in
         # chunks of the engine's batch capacity
         outs = []
@@ -99,20 +116,21 @@ class HNN(_DetModule):
         self.save_hyperparameters(logger=False, ignore=["net"])
         self.net = net
         self.net.apply(weights_init)   # frequentist.py:29
-        if p_dropout:
-            raise RuntimeError("MC-dropout is not implemented on the MI355X path (SURVEY.md 8(f))")
         self._prec, self._max_batch = prec, max_batch
         self.adam = adam_hyper_of(optimizer)
         self._val = []
 
     # ---- frequentist.py:39-48
-    def step(self, batch, phase):
+    def step(self, batch, phase, stochastic: bool = False):
+        """frequentist.py:39-48.  `stochastic`: nn.Dropout active (the training step always is: Lightning runs it in train
+        mode; `enable_dropout` + `mc_sampling` turn it on for the other phases, frequentist.py:83-92)."""
         x, y = batch[0].contiguous().float(), batch[1].contiguous().float().reshape(-1)
         if phase == "train":
-            loss, out = self._ensure_engine(self._prec, self._max_batch).det_step(x, y, "gaussian_nll", self.adam)
+            loss, out = self._ensure_engine(self._prec, self._max_batch).det_step(x, y, "gaussian_nll", self.adam,
+                                                                                 dropout=self._next_dropout())
             loss = loss[0]
         else:
-            out = self.forward(x)
+            out = self.forward(x, self._next_dropout() if stochastic else None)
             if phase == "predict":
                 return out[:, 0], out[:, 1]
             loss = F.gaussian_nll_loss(out[:, 0], y, torch.square(out[:, 1]))
@@ -128,9 +146,31 @@ class HNN(_DetModule):
         self.log("sharp/train", sharpness(scale), on_step=False, on_epoch=True)
         return loss
 
+    # ---- frequentist.py:60-81
+    def mc_sampling(self, batch, mc_samples: int, phase: str, agg: bool = True):
+        losses, locs, scales = [], [], []
+        for _ in range(mc_samples):
+            if phase == "predict":
+                loc, scale = self.step(batch, phase, stochastic=True)
+            else:
+                loss, loc, scale = self.step(batch, phase, stochastic=True)
+                losses.append(loss)
+            locs.append(loc)
+            scales.append(scale)
+        locs, scales = torch.stack(locs), torch.stack(scales)
+        if phase == "predict":
+            return locs, scales
+        loss = torch.stack(losses).mean(0)
+        if agg:
+            return loss, locs.mean(0), scales.pow(2).mean(0).add(locs.var(0)).sqrt()
+        return loss, locs, scales
+
     # ---- frequentist.py:83-113
     def validation_step(self, batch, batch_idx):
-        loss, loc, scale = self.step(batch, "val")
+        if self.net.dropout > 0:
+            loss, loc, scale = self.mc_sampling(batch, self.hparams.mc_samples, phase="val")
+        else:
+            loss, loc, scale = self.step(batch, "val")
         out = {"loss": loss, "label": batch[1].float().reshape(-1), "pred": loc, "std": scale}
         self._val.append(out)
         return out
@@ -150,7 +190,12 @@ class HNN(_DetModule):
     # ---- frequentist.py:115-134
     def test_step(self, batch, batch_idx):
         y = batch[1].float().reshape(-1)
-        loss, loc, scale = self.step(batch, "test")
+        if self.net.dropout > 0:
+            loss, locs, scales = self.mc_sampling(batch, self.hparams.mc_samples, phase="test", agg=False)
+            ep_var, al_var = locs.var(0), (scales**2).mean(0)
+            scale, loc = al_var.add(ep_var).sqrt(), locs.mean(0)
+        else:
+            loss, loc, scale = self.step(batch, "test")
         self.log("nll/test", loss)
         self.log("mse/test", F.mse_loss(loc, y))
         self.log("rmsce/test", rms_calibration_error(loc, scale, y))
@@ -158,8 +203,16 @@ class HNN(_DetModule):
 
     # ---- frequentist.py:136-151
     def predict_step(self, batch, batch_idx, dataloader_idx=0):
-        loc, scale = self.step(batch, "predict")
-        return {"labels": batch[1].cpu().numpy(), "preds": loc.cpu().numpy(), "stds": scale.cpu().numpy()}
+        pred = {"labels": batch[1].cpu().numpy()}
+        if self.net.dropout > 0:
+            locs, scales = self.mc_sampling(batch, self.hparams.mc_samples, phase="predict", agg=False)
+            ep_var, al_var = locs.var(0), (scales**2).mean(0)
+            scale, loc = al_var.add(ep_var).sqrt(), locs.mean(0)
+            pred["ep_vars"], pred["al_vars"] = ep_var.cpu().numpy(), al_var.cpu().numpy()
+        else:
+            loc, scale = self.step(batch, "predict")
+        pred["preds"], pred["stds"] = loc.cpu().numpy(), scale.cpu().numpy()
+        return pred
 
     def on_fit_start(self) -> None:
         self._ensure_engine(self._prec, self._max_batch)

@@ -43,8 +43,12 @@ class Inception(nn.Module):
         assert n_features == 18, "Inception is defined for 18 features (nets/inception.py:160-162)"
         if activation != "relu":
             raise ValueError("the MI355X path implements the relu network every reference config uses")
-        if dropout:
-            raise ValueError("dropout > 0 belongs to the MC-dropout sibling (out of scope, SURVEY.md §8(f))")
+        # dropout > 0 (MC-dropout sibling, conf/model/mcd.yaml): the reference appends nn.Dropout(dropout / 4) to every branch
+        # of both blocks and nn.Dropout(dropout) behind the hidden layer (inception.py:48-52,119-123,205-207).  They carry no
+        # parameters (same state_dict keys); on this path the masks are drawn inside the HIP kernels (bnn_det_step /
+        # bnn_det_forward), so the torch container only records the rate - its eager forward() is the eval-mode network.
+        if not 0 <= dropout < 1:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout}")
         self.win_length, self.n_features, self.out_size, self.dropout = win_length, n_features, out_size, dropout
         self.layers = nn.Sequential(
             InceptionModule(n_features, 27, 27, 27, 27, nn.ReLU, bias),

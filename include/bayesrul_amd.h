@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BNN_ABI_VERSION 2
+#define BNN_ABI_VERSION 3
 
 enum {
   BNN_OK = 0,
@@ -118,7 +118,7 @@ typedef struct BnnElboOut {
 int bnn_version(void);
 const char* bnn_last_error(void);
 /* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
- * 0 BnnPlanDesc, 1 BnnBuffers, 2 BnnNoise, 3 BnnElboArgs, 4 BnnAdamArgs, 5 BnnElboOut, 6 BnnDetArgs */
+ * 0 BnnPlanDesc, 1 BnnBuffers, 2 BnnNoise, 3 BnnElboArgs, 4 BnnAdamArgs, 5 BnnElboOut, 6 BnnDetArgs, 7 BnnDropout */
 size_t bnn_abi_sizeof(int which);
 
 /* ---- plan: replaces BNN.define_bnn / on_fit_start bookkeeping (bayesian.py:45-132) ---- */
@@ -181,13 +181,29 @@ int bnn_elbo_evaluate(BnnPlan* plan, const BnnElboArgs* a, const BnnNoise* noise
  *                (eps = 1e-6, var clamped without gradient), scale = the net's second output (single softplus)
  *   objective 2: NN.step (:173-178): mean_b (loc - y)^2
  * out->loss receives the mean loss; out->preds [1][B][2] the net outputs.  adam == NULL leaves the gradient in place. */
+/* MC-dropout of the frequentist sibling (conf/experiment/ncmapss_mcd.yaml; nets/inception.py:48-52,119-123,205-207): nn.Dropout
+ * behind every branch of both inception blocks (rate p / 4) and behind the hidden layer's ReLU (rate p); an element is kept
+ * with probability 1 - rate and scaled by 1 / (1 - rate).  Exact-fp32 Inception plans only.  The keep masks come from the
+ * Philox stream (seed, step) or, for parity runs, from injected buffers (1 keep / 0 drop; all three or none). */
+typedef struct BnnDropout {
+  double p;                /* net.dropout; 0 = off */
+  uint64_t seed, step;
+  const float* keep_act1;  /* [B*W][128]: block 1, channel c of branch b at 32 b + c */
+  const float* keep_act2;  /* [B*W][80]:  block 2, the concatenation order of its branches (16, 16, 16, 32) */
+  const float* keep_h;     /* [B][64] */
+} BnnDropout;
+
 typedef struct BnnDetArgs {
   const float* x;          /* [B][W][F] */
   const float* y;          /* [B] */
   int32_t batch;
   int32_t objective;       /* 1 gaussian NLL (HNN), 2 MSE (NN) */
+  const BnnDropout* dropout;   /* NULL: none (HNN.training_step runs the net in train mode: dropout active, frequentist.py:50) */
 } BnnDetArgs;
 int bnn_det_step(BnnPlan* plan, const BnnDetArgs* a, const BnnAdamArgs* adam, const BnnElboOut* out, void* stream);
+/* net(x) with weights = mu (frequentist.py:39-42, the forward of HNN.step), dropout active when given: one pass of
+ * HNN.mc_sampling (frequentist.py:60-81).  preds_b2 = [B][2] net outputs (loc, scale). */
+int bnn_det_forward(BnnPlan* plan, const float* x, int32_t batch, const BnnDropout* dropout, float* preds_b2, void* stream);
 
 /* A16: bnn.predict(x, num_predictions=S, aggregate=False) + the aggregation of
  * predict_step / test_step (bayesian.py:203-250): out4 = [4][B] (preds, stds, ep_vars, al_vars);

@@ -174,9 +174,121 @@ def deepens():
     print("deepens", one.stds.values[:3], [g.model.iloc[0] for g in gens])
 
 
+def mcd():
+    """ref_mcd.npz: the reference's MC-dropout sibling (HNN on Inception(dropout = p), conf/experiment/ncmapss_mcd.yaml:21-30)
+    run HERE on CPU with the environment shims of rmsce_and_frequentist().  nn.Dropout draws its masks from torch's
+    generator, which the device path does not reproduce; forward hooks on the nine Dropout modules record the masks each
+    pass used (keep = output != 0 where the input is non-zero; where the input is zero the mask is immaterial: kept), and
+    the fixture holds them in the layout bnn_det_step / bnn_det_forward take as injected masks:
+      two training steps (dropout active, frequentist.py:50): masks, losses, weights after the steps;
+      `mc_sampling(batch, 3, "val")` after them (frequentist.py:60-81, `enable_dropout`): masks of the three passes, the
+      aggregated (loss, loc, scale)."""
+    import functools
+    import inspect
+
+    class LightningModule(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.logged = {}
+
+        def save_hyperparameters(self, *a, logger=True, ignore=None):
+            loc = inspect.currentframe().f_back.f_locals
+            self.hparams = types.SimpleNamespace(
+                **{k: v for k, v in loc.items() if k not in ("self", "__class__") and k not in (ignore or [])})
+
+        def log(self, name, value, **kw):
+            self.logged[name] = float(value)
+
+    _stub("torchinfo", summary=lambda *a, **k: None)
+    _stub("shapely"); _stub("shapely.geometry", Polygon=object, LineString=object)
+    _stub("shapely.ops", polygonize=None, unary_union=None)
+    _stub("uncertainty_toolbox"); _stub("uncertainty_toolbox.metrics_calibration", get_proportion_lists_vectorized=None)
+    _stub("pytorch_lightning", LightningModule=LightningModule)
+    sys.path.insert(0, REF)
+    orig = torch.Tensor.get_device
+    torch.Tensor.get_device = lambda self: self.device
+    try:
+        from bayesrul.models.frequentist import HNN
+        from bayesrul.models.nets.inception import Inception
+        from bayesrul.utils.miscellaneous import enable_dropout
+        p, B, L = 0.241437, 12, 30
+        g = torch.Generator().manual_seed(99)
+        x = torch.randn(B, L, 18, generator=g)
+        y = torch.randint(0, 100, (B,), generator=g).float()
+        torch.manual_seed(0)
+        model = HNN(Inception(L, 18, dropout=p), functools.partial(torch.optim.Adam, lr=0.000772, weight_decay=1e-3),
+                    mc_samples=3, p_dropout=p)
+        sd0 = {k: v.detach().clone().numpy() for k, v in model.net.state_dict().items()}
+        # hooks: module name -> (tensor of block, first channel in the device layout)
+        where = {"layers.0.conv1.branch1_dropout": (1, 0), "layers.0.conv3.branch2_dropout": (1, 32),
+                 "layers.0.conv5.branch3_dropout": (1, 64), "layers.0.convpool.branch4_dropout": (1, 96),
+                 "layers.1.branch1.branch1_dropout": (2, 0), "layers.1.branch2.branch2_dropout": (2, 16),
+                 "layers.1.branch3.branch3_dropout": (2, 32), "layers.1.branch4.branch4_dropout": (2, 48),
+                 "layers.n-1_dropout": (3, 0)}
+        cur = {}
+
+        def hook(name):
+            def f(mod, inp, out):
+                keep = torch.where(inp[0] != 0, out != 0, torch.ones_like(out, dtype=torch.bool)).float()
+                t, c0 = where[name]
+                if t == 3:
+                    cur["kh"] = keep.clone()
+                else:
+                    buf = cur.setdefault("k1" if t == 1 else "k2", torch.ones(B * L, 128 if t == 1 else 80))
+                    kk = keep.permute(0, 2, 1).reshape(B * L, -1)      # [B, C, L] -> rows b * L + l
+                    buf[:, c0:c0 + kk.shape[1]] = kk
+            return f
+        seen = 0
+        for name, mod in model.net.named_modules():
+            if mod.__class__.__name__.startswith("Dropout"):
+                mod.register_forward_hook(hook(name))
+                seen += 1
+        assert seen == 9, seen
+        out = {"x": x.numpy(), "y": y.numpy(), "p": np.float64(p)}
+        opt = model.configure_optimizers()
+        model.train()
+        losses = []
+        for i in range(2):
+            cur.clear()
+            opt.zero_grad()
+            loss = model.training_step((x, y), i)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+            for k in ("k1", "k2", "kh"):
+                out[f"train{i}_{k}"] = cur[k].numpy().copy()
+        out["train_losses"] = np.array(losses)
+        sd1 = {k: v.detach().clone().numpy() for k, v in model.net.state_dict().items()}
+        model.eval()
+        enable_dropout(model.net)
+        passes = []
+        orig_step = model.step
+
+        def step(batch, phase):
+            cur.clear()
+            r = orig_step(batch, phase)
+            passes.append({k: cur[k].numpy().copy() for k in ("k1", "k2", "kh")})
+            return r
+        model.step = step
+        with torch.no_grad():
+            vloss, vloc, vscale = model.mc_sampling((x, y), 3, phase="val")
+        for j, m in enumerate(passes):
+            for k, v in m.items():
+                out[f"val{j}_{k}"] = v
+        out.update(val_loss=np.float64(float(vloss)), val_loc=vloc.numpy(), val_scale=vscale.numpy())
+        np.savez_compressed(os.path.join(HERE, "ref_mcd.npz"), **out, **{"sd0::" + k: v for k, v in sd0.items()},
+                            **{"sd1::" + k: v for k, v in sd1.items()})
+        print("mcd losses", losses, "val", float(vloss), "kept fraction block1", float(out["train0_k1"][:, :27].mean()))
+    finally:
+        torch.Tensor.get_device = orig
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "deepens":
         deepens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "mcd":
+        mcd()
     else:
         main()
         deepens()
+        mcd()

@@ -94,3 +94,19 @@ def synth_batch(B, seed=1234, dtype=torch.float32):
     x = torch.randn(B, 30, 18, generator=g, dtype=dtype)
     y = torch.randint(0, 100, (B,), generator=g).to(dtype)
     return x, y
+
+
+def record(name: str, **vals):
+    """Measured errors of a tolerance test: printed (pytest -s / -rP shows them) and appended to
+    gpurun_out/measured_errors.jsonl, from which the bounds in the tests are set (<= 2x the measured value)."""
+    import json
+    import os
+    row = {"test": name, **{k: (float(v) if not isinstance(v, (str, list, dict)) else v) for k, v in vals.items()}}
+    print("MEASURED", json.dumps(row))
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "measured_errors.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
+    except OSError:
+        pass

@@ -9,14 +9,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _model(guide="normal", ctx="lrt", S=1, prec="bf16x3"):
+
+def _model(guide="normal", ctx="lrt", S=1, prec="bf16x3", seed=0):
     from bayesrul_amd.models.bayesian import BNN
     from bayesrul_amd.models.nets.inception import Inception
     torch.manual_seed(0)
     net = Inception(30, 18)
     return BNN(net, {"lr": 2e-3, "betas": [0.95, 0.999], "clip_norm": 15}, pretrain_epochs=5, mc_samples_train=S,
                mc_samples_eval=4, dataset_size=512, fit_context=ctx, prior_loc=0.0, prior_scale=0.14, guide=guide,
-               q_scale=0.0014, prec=prec, max_batch=64, max_eval_batch=128)
+               q_scale=0.0014, prec=prec, max_batch=64, max_eval_batch=128, seed=seed)
 
 
 @pytest.mark.parametrize("guide,ctx,S", [("normal", "lrt", 1), ("normal", "flipout", 2), ("radial", None, 1)])
@@ -53,6 +54,37 @@ def test_fit_validate_test_predict(guide, ctx, S, tmp_path):
     preds = tr2.predict(model2, val)
     assert set(preds[0]) == {"labels", "ep_vars", "al_vars", "preds", "stds"}
     assert preds[0]["preds"].shape == (128,) and np.all(preds[0]["ep_vars"] >= 0) and np.all(np.isfinite(preds[0]["stds"]))
+
+
+@pytest.mark.parametrize("guide,ctx,S", [("normal", "flipout", 2), ("radial", None, 1)])
+def test_200_step_fit_bf16x3_tracks_the_fp32_plan(guide, ctx, S):
+    """does the split-bf16 plan's looser backward (single-bf16 gradient contractions) matter for a
+    training run?  200 optimiser steps (25 epochs of 8) of the lite Trainer on the learnable synthetic set: the exact-fp32
+    plan and the bf16x3 plan from the same initial weights, shuffles and Philox noise streams, and - as the yardstick of
+    what a difference means for a stochastic training run - the exact-fp32 plan once more with another noise seed.
+    The validation ELBO of the two plans agrees to 1e-4; calibration error, sharpness and MSE (evaluated with 4 MC
+    samples) differ by no more than two runs of the SAME plan with different noise do (factor 1.5 + a floor)."""
+    from bayesrul_amd.data.synthetic import SyntheticWindows
+    from bayesrul_amd.lightning_lite import Trainer
+    from tests.noise_util import record
+    final = {}
+    for tag, prec, seed in (("f32", "f32", 0), ("bf16x3", "bf16x3", 0), ("f32_other_noise", "f32", 1000)):
+        model = _model(guide, ctx, S, prec=prec, seed=seed)
+        train = SyntheticWindows(512, 64, shuffle=True, learnable=True)
+        val = SyntheticWindows(128, 128, seed=7, learnable=True)
+        hist = Trainer(max_epochs=25).fit(model, train, val)
+        final[tag] = hist[-1]
+        assert hist[-1]["elbo/val"] < hist[0]["elbo/val"]
+        del model
+        torch.cuda.empty_cache()
+    a, b, c = final["f32"], final["bf16x3"], final["f32_other_noise"]
+    keys = ("elbo/val", "mse/val", "rmsce/val", "sharp/val")
+    plan = {k: abs(a[k] - b[k]) for k in keys}     # plan-to-plan, same noise
+    noise = {k: abs(a[k] - c[k]) for k in keys}    # same plan, other noise
+    record(f"fit200[{guide}-{ctx}]", f32={k: a[k] for k in keys}, plan_diff=plan, noise_diff=noise)
+    assert plan["elbo/val"] <= 1e-4 * abs(a["elbo/val"]), (a, b)   # measured 3e-5 .. 4e-5
+    for k, floor in (("mse/val", 0.02 * abs(a["mse/val"])), ("rmsce/val", 0.02), ("sharp/val", 0.02 * abs(a["sharp/val"]))):
+        assert plan[k] <= 1.5 * noise[k] + floor, (k, plan[k], noise[k], a, b, c)
 
 
 def test_lightning_progress_poke_and_resume(tmp_path):
@@ -137,7 +169,7 @@ def test_import_pyro_shaped_param_store():
     assert torch.equal(model.engine.log_scale("last.bias").cpu(), params["net_guide.net.last.bias.scale"])
 
 
-@pytest.mark.parametrize("kind,prec,tol", [("hnn", "f32", 2e-4), ("nn", "f32", 2e-4), ("hnn", "bf16x3", 5e-2)])
+@pytest.mark.parametrize("kind,prec,tol", [("hnn", "f32", 2e-5), ("nn", "f32", 2e-5), ("hnn", "bf16x3", 1e-3)])
 def test_frequentist_siblings_match_reference_steps(kind, prec, tol, golden_dir):
     """HNN / NN (bayesrul/models/frequentist.py:39-58,157-188) on the device kernels against three optimiser steps of
     the reference's own classes (tests/golden/make_golden.py: ref_{hnn,nn}_steps.npz; torch.optim.Adam with weight
@@ -160,18 +192,35 @@ def test_frequentist_siblings_match_reference_steps(kind, prec, tol, golden_dir)
     for i in range(3):
         losses.append(float(model.training_step((x, y), i)))
     ref = z["losses"]
-    for a, b in zip(losses, ref):
-        assert abs(a - b) <= max(tol, 5 * tol if prec != "f32" else tol) * abs(b), (losses, ref.tolist())
+    from tests.noise_util import record
+    record(f"frequentist[{kind}-{prec}]", loss_rel=[abs(a - b) / abs(b) for a, b in zip(losses, ref)])
+    # bf16x3: the first loss is evaluated on identical weights (forward error only: measured 7e-6); the later ones after
+    # updates driven by single-bf16 gradients (measured 4.3e-4).  f32: measured <= 1e-5 at every step.
+    for i, (a, b) in enumerate(zip(losses, ref)):
+        bound = tol if prec == "f32" else (2e-5 if i == 0 else 1e-3)
+        assert abs(a - b) <= bound * abs(b), (i, losses, ref.tolist())
     if kind == "hnn":
         logs = model.collect_logs()
-        assert abs(logs["mse/train"] - float(z["mse"].mean())) <= 10 * tol * float(z["mse"].mean())
+        assert abs(logs["mse/train"] - float(z["mse"].mean())) <= 1e-3 * float(z["mse"].mean())
     sd = model.sync_net().state_dict()
+    disp, tot_num, tot_den = {}, 0.0, 0.0
     for k in sd:
         if k.startswith(("layers", "last")):
             d0, d1 = torch.from_numpy(z["sd0::" + k]), torch.from_numpy(z["sd1::" + k])
             # Adam moves every element by ~lr per step: compare the displacement
             num, den = (sd[k].cpu() - d1).norm(), (d1 - d0).norm()
-            assert float(num) <= (0.02 if prec == "f32" else 0.35) * float(den), (k, float(num), float(den))
+            disp[k] = float(num) / float(den)
+            # f32: measured 1e-5.  bf16x3: Adam moves every element by ~lr per step whatever the size of its gradient, so an
+            # element whose gradient is within the bf16 backward's noise of zero moves the OTHER way: on a 16-element bias site
+            # two such elements are 0.29 of the displacement's norm (measured worst site, layers.1.branch3.2.bias); the
+            # whole-vector figure is asserted below
+            assert float(num) <= (1e-4 if prec == "f32" else 0.35) * float(den), (k, float(num), float(den))
+            tot_num += float(num) ** 2
+            tot_den += float(den) ** 2
+    glob = (tot_num / tot_den) ** 0.5
+    record(f"frequentist_displacement_global[{kind}-{prec}]", rel_l2=glob)
+    assert glob <= (1e-4 if prec == "f32" else 0.042), glob   # measured 7.9e-6 (f32), 2.1e-2 (bf16x3)
+    record(f"frequentist_displacement[{kind}-{prec}]", worst=max(disp.values()), site=max(disp, key=disp.get))
 
 
 def test_gather_windows_bounds():
@@ -181,3 +230,95 @@ def test_gather_windows_bounds():
     xo, yo = st.gather(torch.tensor([4, 5, -1, 0]))
     assert torch.equal(xo[0].cpu(), x[4]) and torch.equal(xo[3].cpu(), x[0])
     assert torch.isnan(xo[1]).all() and torch.isnan(xo[2]).all() and torch.isnan(yo[1:3]).all()
+
+
+def test_mc_dropout_matches_reference_with_injected_masks(golden_dir):
+    """The MC-dropout sibling (frequentist.py:50-92 on Inception(dropout = p), conf/experiment/ncmapss_mcd.yaml) against the
+    REFERENCE's own classes (tests/golden/make_golden.py mcd(): ref_mcd.npz).  nn.Dropout's masks come from torch's
+    generator there; the fixture holds the masks every pass used and the device path takes them as injected keep masks:
+    two training steps (dropout active) - losses and weights - then the three stochastic passes of
+    `mc_sampling(batch, 3, "val")` - aggregated loss / loc / scale."""
+    import torch.nn.functional as F
+    from bayesrul_amd.models.frequentist import HNN
+    from bayesrul_amd.models.nets.inception import Inception
+    from tests.noise_util import record
+    z = np.load(os.path.join(golden_dir, "ref_mcd.npz"))
+    p = float(z["p"])
+    net = Inception(30, 18, dropout=p)
+    model = HNN(net, {"lr": 0.000772, "weight_decay": 1e-3}, mc_samples=3, p_dropout=p, prec="f32", max_batch=12)
+    net.load_state_dict({k[5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd0::")})
+    model.to("cuda:0")
+    x, y = torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["y"]).cuda()
+    eng = model._ensure_engine("f32", 12)
+    keep = lambda tag: tuple(torch.from_numpy(z[f"{tag}_{k}"]) for k in ("k1", "k2", "kh"))
+    losses = []
+    for i in range(2):
+        loss, _ = eng.det_step(x, y, "gaussian_nll", model.adam, dropout=eng._dropout(p, 0, 0, keep(f"train{i}")))
+        losses.append(float(loss[0]))
+    ref = z["train_losses"]
+    record("mcd_train", loss_rel=[abs(a - b) / abs(b) for a, b in zip(losses, ref)])
+    for a, b in zip(losses, ref):
+        assert abs(a - b) <= 2e-5 * abs(b), (losses, ref.tolist())
+    sd = model.sync_net().state_dict()
+    tn = td = 0.0
+    for k in sd:
+        if k.startswith(("layers", "last")):
+            d0, d1 = torch.from_numpy(z["sd0::" + k]), torch.from_numpy(z["sd1::" + k])
+            tn += float((sd[k].cpu() - d1).norm()) ** 2
+            td += float((d1 - d0).norm()) ** 2
+    record("mcd_train_displacement", rel_l2=(tn / td) ** 0.5)
+    assert (tn / td) ** 0.5 <= 1e-3, (tn / td) ** 0.5
+    # mc_sampling(batch, 3, "val"): three stochastic passes with the recorded masks
+    locs, scales, ls = [], [], []
+    for j in range(3):
+        out = eng.det_forward(x, eng._dropout(p, 0, 0, keep(f"val{j}")))
+        locs.append(out[:, 0])
+        scales.append(out[:, 1])
+        ls.append(F.gaussian_nll_loss(out[:, 0], y, torch.square(out[:, 1])))
+    locs, scales = torch.stack(locs), torch.stack(scales)
+    loc, scale = locs.mean(0), scales.pow(2).mean(0).add(locs.var(0)).sqrt()
+    record("mcd_val", loss_rel=abs(float(torch.stack(ls).mean()) - float(z["val_loss"])) / abs(float(z["val_loss"])),
+           loc=float((loc.cpu() - torch.from_numpy(z["val_loc"])).abs().max()),
+           scale=float((scale.cpu() - torch.from_numpy(z["val_scale"])).abs().max()))
+    assert abs(float(torch.stack(ls).mean()) - float(z["val_loss"])) <= 2e-5 * abs(float(z["val_loss"]))
+    assert torch.allclose(loc.cpu(), torch.from_numpy(z["val_loc"]), rtol=2e-5, atol=1e-6)
+    assert torch.allclose(scale.cpu(), torch.from_numpy(z["val_scale"]), rtol=2e-5, atol=1e-6)
+
+
+def test_mc_dropout_philox_masks_and_hooks():
+    """The kernels' own masks (Philox): the share of block-2 outputs a stochastic pass zeroes beyond the ReLU zeros is the
+    dropout rate p / 4 (nets/inception.py:119-123), passes differ, and the HNN hooks run the reference's branches
+    (`mc_sampling` in validation / test / predict when net.dropout > 0)."""
+    from bayesrul_amd import _native as N
+    from bayesrul_amd.models.frequentist import HNN
+    from bayesrul_amd.models.nets.inception import Inception
+    torch.manual_seed(0)
+    p = 0.4
+    net = Inception(30, 18, dropout=p)
+    model = HNN(net, {"lr": 1e-3, "weight_decay": 1e-3}, mc_samples=5, p_dropout=p, prec="f32", max_batch=256)
+    model.to("cuda:0")
+    x = torch.randn(256, 30, 18, device="cuda:0")
+    y = torch.randint(0, 100, (256,), device="cuda:0").float()
+    eng = model._ensure_engine("f32", 256)
+    eng.det_forward(x, None)
+    a0 = eng.tensor(N.T_ACT2)[:256 * 30]
+    eng.det_forward(x, eng._dropout(p, 7, 1))
+    a1 = eng.tensor(N.T_ACT2)[:256 * 30]
+    # block-1 dropout changes the block-2 pre-activations too, so compare the zero SHARES, not positions
+    z0, z1 = float((a0 == 0).float().mean()), float((a1 == 0).float().mean())
+    expect = z0 + (1 - z0) * p / 4
+    assert abs(z1 - expect) < 0.02, (z0, z1, expect)
+    kept = a1[a1 != 0].abs().mean() / a0[a0 != 0].abs().mean()
+    assert 0.8 < float(kept) < 1.4     # survivors are scaled by 1 / (1 - p / 4)
+    o1, o2 = eng.det_forward(x, eng._dropout(p, 7, 1)), eng.det_forward(x, eng._dropout(p, 7, 2))
+    assert torch.equal(o1, eng.det_forward(x, eng._dropout(p, 7, 1))) and not torch.equal(o1, o2)
+    # hooks
+    l0 = float(model.training_step((x, y), 0))
+    out = model.validation_step((x, y), 0)
+    assert out["pred"].shape == (256,) and torch.isfinite(out["std"]).all() and math.isfinite(l0)
+    model.test_step((x, y), 0)
+    pr = model.predict_step((x, y), 0)
+    assert set(pr) == {"labels", "ep_vars", "al_vars", "preds", "stds"} and np.all(pr["ep_vars"] > 0)
+    # refused where it cannot run
+    with pytest.raises(RuntimeError):
+        HNN(Inception(30, 18, dropout=p), {"lr": 1e-3}, mc_samples=2, p_dropout=p, prec="bf16x3").to("cuda:0").on_fit_start()

@@ -15,7 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import restatement as R
-from tests.noise_util import flat, oracle_cfg, rel_l2, synth_batch, to_injected
+from tests.noise_util import flat, oracle_cfg, record, rel_l2, synth_batch, to_injected
 
 HYP = {"lrt": (0.138793, 0.001351, 8.57e-4), "flipout": (0.198768, 0.000214, 9.48e-4),
        "radial": (0.092516, 0.001241, 9.56e-4)}
@@ -27,6 +27,14 @@ def _engine(net, mode, prec, S, B, **kw):
     guide = "radial" if mode == "radial" else "normal"
     ctx = mode if mode in ("lrt", "flipout") else None
     return SviEngine(net=net, guide=guide, fit_context=ctx, prec=prec, max_particles=S, max_batch=B, **kw)
+
+
+# bf16x3 plan against the f64 oracle / the exact-fp32 plan: bounds = 2 x the values measured on MI355X (printed by
+# tests.noise_util.record into gpurun_out/measured_errors.jsonl), (mu, rho) each
+LIN_TOL = (1.1e-2, 1.3e-2)    # per-site gradients, Linear net LRT: measured worst site 5.2e-3 / 6.4e-3
+# 20-step parameter displacement vs the oracle's: measured d mu 1.0e-2 .. 1.1e-2, d rho 2.6e-3 (radial) .. 8.0e-3 (lrt)
+TRAJ_TOL = {"flipout": (2.2e-2, 1.1e-2), "lrt": (2.1e-2, 1.6e-2), "radial": (2.1e-2, 5.2e-3)}
+FULL_TOL = (2.5e-3, 2.2e-3)   # full-size radial (S = 20, B = 1000): bf16x3 vs exact-fp32 gradients, measured 1.2e-3 / 1.1e-3
 
 
 @pytest.mark.parametrize("B", [100, 1001])
@@ -46,12 +54,16 @@ def test_linear_net_lrt_bf16x3_matches_oracle(B):
     res, preds = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, noise=to_injected(eng, cfg, noise, B),
                           want_preds=True)
     loss_o, aux = st.loss_and_grads(x, y, noise)
-    assert abs(float(res[0]) - float(loss_o)) <= 2e-4 * abs(float(loss_o)), (float(res[0]), float(loss_o))
+    assert abs(float(res[0]) - float(loss_o)) <= 1e-5 * abs(float(loss_o)), (float(res[0]), float(loss_o))   # measured 1.5e-6
     assert torch.allclose(preds.cpu().double(), aux["preds"], rtol=2e-3, atol=1e-4)
     g = eng.grad.cpu()
+    emu = {s: rel_l2(g[off:off + num], st.mu[s].grad) for s, off, num in eng.sites}
+    erho = {s: rel_l2(g[eng.P + off:eng.P + off + num], st.rho[s].grad) for s, off, num in eng.sites}
+    record(f"linear_lrt_bf16x3[{B}]", loss_rel=abs(float(res[0]) - float(loss_o)) / abs(float(loss_o)),
+           worst_mu=max(emu.values()), worst_rho=max(erho.values()))
     for s, off, num in eng.sites:
-        assert rel_l2(g[off:off + num], st.mu[s].grad) < 3e-2, ("mu", s, rel_l2(g[off:off + num], st.mu[s].grad))
-        assert rel_l2(g[eng.P + off:eng.P + off + num], st.rho[s].grad) < 8e-2, ("rho", s)
+        assert emu[s] < LIN_TOL[0], ("mu", s, emu[s])
+        assert erho[s] < LIN_TOL[1], ("rho", s, erho[s])
 
 
 @pytest.mark.parametrize("mode", ["flipout", "lrt", "radial"])
@@ -78,13 +90,14 @@ def test_bf16x3_adam_trajectory_tracks_oracle(mode):
         lo, _ = st.step(x, y, noise)
         err = abs(float(res[0]) - lo) / abs(lo)
         worst = max(worst, err)
-        assert err <= 1e-3, (mode, k, float(res[0]), lo)
+        assert err <= 7e-4, (mode, k, float(res[0]), lo)   # measured worst 1.7e-4 .. 3.5e-4 over the 20 steps (north star 1e-3)
     m0 = flat(mu0, "inception")
     d_dev, d_orc = eng.mu.cpu().double() - m0, flat(st.mu, "inception") - m0
     r_dev, r_orc = eng.rho.cpu().double() - math.log(qs), flat(st.rho, "inception") - math.log(qs)
     # after 20 steps every element has moved ~20 lr; sign disagreements of near-zero gradients dominate the drift
-    assert rel_l2(d_dev, d_orc) < 0.12, (mode, rel_l2(d_dev, d_orc), worst)
-    assert rel_l2(r_dev, r_orc) < 0.25, (mode, rel_l2(r_dev, r_orc), worst)
+    record(f"bf16x3_trajectory[{mode}]", worst_elbo_rel=worst, d_mu=rel_l2(d_dev, d_orc), d_rho=rel_l2(r_dev, r_orc))
+    assert rel_l2(d_dev, d_orc) < TRAJ_TOL[mode][0], (mode, rel_l2(d_dev, d_orc), worst)
+    assert rel_l2(r_dev, r_orc) < TRAJ_TOL[mode][1], (mode, rel_l2(r_dev, r_orc), worst)
 
 
 def test_full_size_radial_s20_properties():
@@ -110,11 +123,13 @@ def test_full_size_radial_s20_properties():
         del eng
         torch.cuda.empty_cache()
     a, b = out["f32"][0], out["bf16x3"][0]
-    assert abs(float(a[0] - b[0])) <= 1e-4 * abs(float(a[0])), (a, b)
+    assert abs(float(a[0] - b[0])) <= 1e-6 * abs(float(a[0])), (a, b)   # measured 6.7e-8
     assert abs(float(a[1] - b[1])) <= 1e-6 * abs(float(a[1]))
     P = R.n_params("inception")
-    assert rel_l2(out["bf16x3"][1][:P], out["f32"][1][:P]) < 3e-2
-    assert rel_l2(out["bf16x3"][1][P:2 * P], out["f32"][1][P:2 * P]) < 8e-2
+    record("full_size_radial_s20", elbo_rel=abs(float(a[0] - b[0])) / abs(float(a[0])),
+           dmu=rel_l2(out["bf16x3"][1][:P], out["f32"][1][:P]), drho=rel_l2(out["bf16x3"][1][P:2 * P], out["f32"][1][P:2 * P]))
+    assert rel_l2(out["bf16x3"][1][:P], out["f32"][1][:P]) < FULL_TOL[0]
+    assert rel_l2(out["bf16x3"][1][P:2 * P], out["f32"][1][P:2 * P]) < FULL_TOL[1]
 
 
 def test_full_size_predictive_pass_s100():

@@ -12,7 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import restatement as R
-from tests.noise_util import flat, from_injected, oracle_cfg, rel_l2, synth_batch, to_injected
+from tests.noise_util import record, flat, from_injected, oracle_cfg, rel_l2, synth_batch, to_injected
 
 HYP = {"lrt": (0.138793, 0.001351, 8.57e-4), "flipout": (0.198768, 0.000214, 9.48e-4),
        "radial": (0.092516, 0.001241, 9.56e-4), "normal": (0.15, 0.002, 9e-4)}
@@ -37,6 +37,15 @@ def _setup(net, mode, prec, S, B, q_boost=1.0, seed=0):
     x, y = synth_batch(B)
     noise = R.make_noise(cfg, B, S, torch.Generator().manual_seed(4321))
     return eng, cfg, st, x, y, noise, (ps, qs, lr)
+
+
+# bf16x3 plan, gradients against the f64 oracle (rel-L2): bounds = 2 x the values measured on MI355X (gpurun_out/
+# measured_errors.jsonl of the round-3 run, printed by tests.noise_util.record), per estimator: (d mu, d rho).  The backward
+# contractions are single bf16; the exact-fp32 plan - the default and the judged one - is held to 1e-3 per site.
+# measured (S = 2, B = 100, shipped hyper-parameters): whole-vector d mu 1.3e-3 .. 1.6e-3, d rho 2.4e-4 (radial) .. 5.9e-3 (lrt);
+# worst single site (q_scale x 5) d mu 4.1e-3 .. 8.6e-3, d rho 5.6e-3 (radial) .. 2.2e-2 (flipout, layers.1.branch2.0.weight)
+GRAD_TOL = {"lrt": (3.1e-3, 1.2e-2), "flipout": (3.1e-3, 6.1e-3), "radial": (2.6e-3, 5e-4)}
+SITE_TOL = {"lrt": (1.8e-2, 3.5e-2), "flipout": (1.4e-2, 4.5e-2), "radial": (8.2e-3, 1.2e-2)}
 
 
 @pytest.mark.parametrize("mode", ["lrt", "flipout", "radial", "normal"])
@@ -67,7 +76,7 @@ def test_step_f32_matches_oracle(net, mode):
 
 @pytest.mark.parametrize("mode", ["lrt", "flipout", "radial"])
 def test_step_bf16x3_elbo_within_tolerance(mode):
-    """north star: ELBO within 1e-3 relative of the reference arithmetic (we hold 1e-4) at the
+    """north star: ELBO within 1e-3 relative of the reference arithmetic (we hold 1e-5) at the
     shipped hyper-parameters, batch 100."""
     S, B = 2, 100
     eng, cfg, st, x, y, noise, (ps, qs, lr) = _setup("inception", mode, "bf16x3", S, B)
@@ -75,13 +84,16 @@ def test_step_bf16x3_elbo_within_tolerance(mode):
     res, preds = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, noise=inj, want_preds=True)
     loss_o, aux = st.loss_and_grads(x, y, noise)
     res = res.cpu().double()
-    assert abs(float(res[0]) - float(loss_o)) <= 1e-4 * abs(float(loss_o)), (float(res[0]), float(loss_o))
+    # measured 1.1e-6 .. 3.3e-6 (north star: 1e-3)
+    assert abs(float(res[0]) - float(loss_o)) <= 1e-5 * abs(float(loss_o)), (float(res[0]), float(loss_o))
     assert torch.allclose(preds.cpu().double(), aux["preds"], rtol=2e-3, atol=1e-4)
     g = eng.grad.cpu()
     gmu = torch.cat([st.mu[s].grad.flatten() for s, _ in R.site_shapes("inception")])
     grho = torch.cat([st.rho[s].grad.flatten() for s, _ in R.site_shapes("inception")])
-    assert rel_l2(g[:eng.P], gmu) < 3e-2, rel_l2(g[:eng.P], gmu)
-    assert rel_l2(g[eng.P:2 * eng.P], grho) < 0.15, rel_l2(g[eng.P:2 * eng.P], grho)
+    record(f"step_bf16x3_elbo[{mode}]", loss_rel=abs(float(res[0]) - float(loss_o)) / abs(float(loss_o)),
+           dmu=rel_l2(g[:eng.P], gmu), drho=rel_l2(g[eng.P:2 * eng.P], grho))
+    assert rel_l2(g[:eng.P], gmu) < GRAD_TOL[mode][0], rel_l2(g[:eng.P], gmu)
+    assert rel_l2(g[eng.P:2 * eng.P], grho) < GRAD_TOL[mode][1], rel_l2(g[eng.P:2 * eng.P], grho)
 
 
 @pytest.mark.parametrize("mode", ["lrt", "flipout", "radial"])
@@ -103,9 +115,13 @@ def test_step_bf16x3_per_site_gradients_and_reproducibility(mode):
     (l0, g0, p0), (l1, g1, p1) = runs
     assert l0 == l1 and torch.equal(p0, p1)
     assert rel_l2(g1, g0.double()) < 1e-6
+    emu = {s: rel_l2(g0[off:off + num], st.mu[s].grad) for s, off, num in eng.sites}
+    erho = {s: rel_l2(g0[eng.P + off:eng.P + off + num], st.rho[s].grad) for s, off, num in eng.sites}
+    record(f"step_bf16x3_per_site[{mode}]", worst_mu=max(emu.values()), worst_mu_site=max(emu, key=emu.get),
+           worst_rho=max(erho.values()), worst_rho_site=max(erho, key=erho.get), run_to_run=rel_l2(g1, g0.double()))
     for s, off, num in eng.sites:
-        assert rel_l2(g0[off:off + num], st.mu[s].grad) < 3e-2, ("mu", s)
-        assert rel_l2(g0[eng.P + off:eng.P + off + num], st.rho[s].grad) < 8e-2, ("rho", s)
+        assert emu[s] < SITE_TOL[mode][0], ("mu", s, emu[s])
+        assert erho[s] < SITE_TOL[mode][1], ("rho", s, erho[s])
 
 
 @pytest.mark.parametrize("mode", ["lrt", "radial"])

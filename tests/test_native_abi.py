@@ -32,7 +32,7 @@ def test_header_symbols_exported(lib):
 def test_struct_sizes_match(lib):
     for i, st in enumerate(N._ABI_STRUCTS):
         assert lib.bnn_abi_sizeof(i) == C.sizeof(st)
-    assert lib.bnn_version() == N.ABI_VERSION == 2
+    assert lib.bnn_version() == N.ABI_VERSION == 3
 
 
 @pytest.mark.parametrize("net", ["inception", "linear"])
