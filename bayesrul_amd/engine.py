@@ -63,7 +63,7 @@ class SviEngine:
     RESULT_SLOTS = 256   # ring of (loss, kl, loglik) result slots of step(): see its docstring
 
     def __init__(self, net: str = "inception", guide: str = "normal", fit_context: Optional[str] = "lrt",
-                 prec: str = "bf16x3", max_particles: int = 1, max_batch: int = 100, win_length: int = 30,
+                 prec: str = "f32", max_particles: int = 1, max_batch: int = 100, win_length: int = 30,
                  n_features: int = 18, device: str | torch.device = "cuda:0", max_windows: int = 0):
         self.lib = N.load()
         self.device = torch.device(device)

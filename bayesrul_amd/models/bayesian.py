@@ -78,7 +78,7 @@ class VariationalBNN:
 class BNN(_Base):
     def __init__(self, net: torch.nn.Module, optimizer, pretrain_epochs: int, mc_samples_train: int,
                  mc_samples_eval: int, dataset_size: int, fit_context: Optional[str], prior_loc: float,
-                 prior_scale: float, guide: str, q_scale: float, prec: str = "bf16x3", max_batch: int = 1000,
+                 prior_scale: float, guide: str, q_scale: float, prec: str = "auto", max_batch: int = 1000,
                  max_eval_batch: int = 10000, seed: int = 0, guide_kwargs: Optional[dict] = None):
         super().__init__()
         self.save_hyperparameters(logger=False, ignore=["net"])
@@ -115,7 +115,14 @@ class BNN(_Base):
         S = max(hp.mc_samples_train, hp.mc_samples_eval)
         B = max(hp.max_batch, 1)
         eval_windows = max(S * B, min(hp.mc_samples_eval * hp.max_eval_batch, 200_000))
-        self.engine = SviEngine(net=net_kind, guide=hp.guide, fit_context=hp.fit_context, prec=hp.prec, max_particles=S,
+        # precision plan: "f32" = exact-fp32 MFMA, the reference's arithmetic (conf/trainer/default.yaml:8-12 trains in fp32);
+        # "bf16x3" = split-bf16 (faster, looser gradients: tests/test_gpu_bnn_surface.py::test_200_step_fit_...).  "auto": f32
+        # wherever fused fp32 kernels exist (Inception with Flipout / radial / plain sampling); LRT and the Linear net have
+        # fused kernels on the bf16x3 plan only (their f32 plan runs the generic per-group kernels, ~10x slower)
+        prec = hp.prec
+        if prec == "auto":
+            prec = "f32" if (net_kind == "inception" and hp.fit_context != "lrt") else "bf16x3"
+        self.engine = SviEngine(net=net_kind, guide=hp.guide, fit_context=hp.fit_context, prec=prec, max_particles=S,
                                 max_batch=max(B, hp.max_eval_batch), win_length=self.net.win_length,
                                 n_features=self.net.n_features, device=self.device, max_windows=eval_windows)
         self.engine.init_params(self._initial_means(), 1.0)
