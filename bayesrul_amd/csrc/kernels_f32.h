@@ -465,8 +465,7 @@ __global__ __launch_bounds__(TF_THREADS) void tf_fwd_kernel(const TfArgs A) {
 
 // fp32 planes [rows][20] of the raw windows and of their MaxPool1d(3,1,1) copy (block 1's pooled branch,
 // inception.py:41-46); channels 18, 19 zero.  rows = B * L, pooling stays inside a window.  One thread per 4 channels.
-__global__ void xf_planes_kernel(const float* x, float* xp, float* xpp, long rows, int L, int F) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void xf_planes_dev(const float* x, float* xp, float* xpp, long rows, int L, int F, long idx) {
   if (idx >= rows * 5) return;
   const long r = idx / 5;
   const int c0 = (int)(idx - r * 5) * 4;
@@ -485,6 +484,9 @@ __global__ void xf_planes_kernel(const float* x, float* xp, float* xpp, long row
   }
   *(f32x4*)(xp + r * TF_XC + c0) = v;
   *(f32x4*)(xpp + r * TF_XC + c0) = q;
+}
+__global__ void xf_planes_kernel(const float* x, float* xp, float* xpp, long rows, int L, int F) {
+  xf_planes_dev(x, xp, xpp, rows, L, F, (long)blockIdx.x * blockDim.x + threadIdx.x);   // rows * 5 threads
 }
 
 // ==========================================================================================
@@ -1776,6 +1778,11 @@ struct DenseFinF32Args {
   uint64_t drop_seed;
   uint32_t drop_step;
   const float* keep_h;  // injected keep mask [rows][64]; null: Philox
+  // the last layer's gradient elements, zeroed here for the head launch's atomics (training step): per particle 2 rows of
+  // KP in the weight images (slots A and B) and 2 biases; null: nothing to zero
+  float* g2_a; float* g2_b; float* g2_ba;
+  long g2_stride; int g2_bstride;
+  int S;
 };
 
 template <int EM>
@@ -1800,6 +1807,12 @@ __global__ __launch_bounds__(256) void densef_fin_kernel(const DenseFinF32Args F
     for (int r = 0; r < 4; ++r) v[r] = ((kb >> r) & 1u) ? v[r] * F.drop_scale : 0.f;
   }
   if (live) *(f32x4*)(F.h + (long)row * 64 + ch) = v;
+  if (F.g2_a && t < F.S * 2 * F.w2_KP) {
+    const int zs = t / (2 * F.w2_KP), ze = t - zs * 2 * F.w2_KP;
+    F.g2_a[F.g2_stride * zs + ze] = 0.f;
+    F.g2_b[F.g2_stride * zs + ze] = 0.f;
+    if (ze < 2) F.g2_ba[(long)F.g2_bstride * zs + ze] = 0.f;
+  }
   float m[2] = {0.f, 0.f}, pz[2] = {0.f, 0.f};
   uint32_t bits = 0;
   if constexpr (FO) bits = F.sg_in[(long)row * F.siw + (ch >> 5)] >> (ch & 31);

@@ -122,11 +122,13 @@ struct StepInputsArgs {
   float* eps; long P; int S; uint64_t eps_seed; uint32_t step;
   float* rad_r; int n_sites;   // radial guide: the S * n_sites radial distances ride on the last weight-noise block
   const float* x; u16* xp[4]; long rows; int L, F;
+  float* xf[2];                // fp32 plan: x | pooled x planes [rows][20] instead of the four bf16 planes (null: bf16)
   SignGenArgs sg;
   unsigned b_x;
   unsigned b_sg[2 * BNN_MAX_LAYERS + 1];
 };
 __device__ __forceinline__ void x_planes4_dev8(const float* x, u16* hi, u16* lo, u16* phi, u16* plo, long rows, int L, int F, long idx8);
+__device__ __forceinline__ void xf_planes_dev(const float* x, float* xp, float* xpp, long rows, int L, int F, long idx);
 
 __global__ __launch_bounds__(256) void step_inputs_kernel(const StepInputsArgs A) {
   const unsigned blk = blockIdx.x;
@@ -151,7 +153,8 @@ __global__ __launch_bounds__(256) void step_inputs_kernel(const StepInputsArgs A
     return;
   }
   if (blk < A.b_sg[0]) {
-    x_planes4_dev8(A.x, A.xp[0], A.xp[1], A.xp[2], A.xp[3], A.rows, A.L, A.F, (long)(blk - A.b_x) * 256 + threadIdx.x);
+    if (A.xf[0]) xf_planes_dev(A.x, A.xf[0], A.xf[1], A.rows, A.L, A.F, (long)(blk - A.b_x) * 256 + threadIdx.x);
+    else x_planes4_dev8(A.x, A.xp[0], A.xp[1], A.xp[2], A.xp[3], A.rows, A.L, A.F, (long)(blk - A.b_x) * 256 + threadIdx.x);
     return;
   }
   int e = 0;

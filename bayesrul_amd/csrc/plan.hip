@@ -687,13 +687,18 @@ static int prepare_noise(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, C
     u16* xp = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
     SI.x = c->fuse_x; SI.rows = (long)B * L; SI.L = L; SI.F = p->d.n_features;
     for (int k = 0; k < 4; ++k) SI.xp[k] = xp + k * plane;
+    const bool f32p = p->d.prec == BNN_PREC_F32;   // fp32 plan: x | pooled x as fp32 [rows][20] (launch_tf_fwd's layout)
+    if (f32p) {
+      SI.xf[0] = (float*)xp;
+      SI.xf[1] = (float*)xp + (size_t)p->d.max_batch * L * TF_XC;
+    }
     unsigned nb = (unsigned)((((p->P + 3) / 4) * S + 255) / 256);
     if (fused_rad) {
       SI.rad_r = ws_f(p, p->o_radr); SI.n_sites = p->n_sites;
       nb += 1;
     }
     SI.b_x = nb;
-    nb += (unsigned)((SI.rows * 4 + 255) / 256);   // 8 channels per thread
+    nb += (unsigned)((SI.rows * (f32p ? 5 : 4) + 255) / 256);   // 8 (bf16 planes) / 4 (fp32 planes) channels per thread
     if (SG) SI.sg = *SG;
     for (int e = 0; e < SI.sg.n; ++e) {
       SI.b_sg[e] = nb;
@@ -2144,6 +2149,12 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
     R.siw = l2.sign_in_words;
     R.sow = l2.sign_out_words;
     R.z = tens_ptr(p, p->z_t, 0);
+    R.g2_a = A.gw_a + l2.w_off;   // zeroed for the head launch's atomics (every other gradient element of a step is stored)
+    R.g2_b = A.gw_b + l2.w_off;
+    R.g2_ba = A.gb_a + l2.bias_off;
+    R.g2_stride = A.gw_stride;
+    R.g2_bstride = A.gb_stride;
+    R.S = A.cg.S;
     if (drop) {
       R.drop_rate = (float)drop->p;
       R.drop_scale = (float)(1.0 / (1.0 - drop->p));
@@ -2151,7 +2162,8 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
       R.drop_step = (uint32_t)drop->step;
       R.keep_h = drop->keep_h;
     }
-    const unsigned fgrid = (unsigned)((R.rows * 16 + 255) / 256);
+    // one thread per (row, 4 channels); at least S * 2 * KP threads for the zeroing (surplus threads redo the last row)
+    const unsigned fgrid = (unsigned)((std::max((long)R.rows * 16, (long)R.S * 2 * l2.KP) + 255) / 256);
     if (em == EM_PLAIN) densef_fin_kernel<EM_PLAIN><<<dim3(fgrid), dim3(256), 0, st>>>(R);
     else densef_fin_kernel<EM_FLIPOUT><<<dim3(fgrid), dim3(256), 0, st>>>(R);
     HIP_TRY(hipGetLastError());
@@ -2362,8 +2374,9 @@ static int prepare_fused_tail(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
   c->last_fused = (trunk_ok(p, c) || tf_ok(p, c)) && p->fwd_fused_last && last_fused_ok(p, c->em, p->n_groups - 2);
   if (!c->last_fused) return 0;
   if (tf_ok(p, c)) {
-    // fp32 plan: the head launch and (with two row ranges per chunk) the dense dW kernel add with atomics
-    BNN_TRY(zero_grad_images(p, c));
+    // fp32 plan: every gradient element of the conv layers (slab reduction) and of the wide dense layer (densef_dw_kernel,
+    // dense_add2_kernel) is STORED; the last layer's few elements, which the head launch adds to, were zeroed by the fin
+    // kernel of the forward: no fill
     c->grads_zeroed = true;
     return 0;
   }
@@ -2686,7 +2699,7 @@ extern "C" int bnn_elbo_step(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* n
   Ctx c;
   BNN_TRY(make_ctx(p, a, nz, stream, true, &c));
   if (!a->with_obs) return fail(BNN_E_INVALID, "bnn_elbo_step needs with_obs = 1");
-  if (trunk_ok(p, &c)) c.fuse_x = a->x;
+  if (trunk_ok(p, &c) || tf_ok(p, &c)) c.fuse_x = a->x;
   BNN_TRY(prepare_noise(p, a, nz, &c));
   BNN_TRY(do_sample(p, a, &c));
   BNN_TRY(do_forward(p, a, &c, a->x));
