@@ -1894,7 +1894,7 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
     return fail(BNN_E_INVALID, "fp32 trunk kernels address rows with 32-bit byte offsets: S*B*L = %ld rows exceed 2^23", (long)c->S * c->B * L);
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_FWD, 0, c->st);
-  ps_.name("tf_fwd_kernel<%d, %s>", c->em, c->train ? "true" : "false");
+  ps_.name("tf_fwd_kernel<%d, %s, %s>", c->em, c->train ? "true" : "false", drop_on(c) ? "true" : "false");
 #define LAUNCH_TF(EMV, TRV)                                                               \
   do {                                                                                    \
     BNN_TRY(set_lds(tf_fwd_kernel<EMV, TRV>, TF_LDS));                                    \
