@@ -35,7 +35,8 @@ enum {
   TF_O_MID = TF_O_A1 + 2 * 2 * TF_PA,  // [2 bufs][MID]
   TF_O_SGN = TF_O_MID + 2 * TF_PB,     // [4 slots][10 layers][8 words]
   TF_O_LUT = TF_O_SGN + 4 * 80 * 4,    // 32 x 16 B: (s_out bit, 4 s_in bits) -> sign masks of a 4-channel fragment
-  TF_LDS = TF_O_LUT + 32 * 16
+  TF_O_WB = TF_O_LUT + 32 * 16,        // LRT: sigma^2 fragments of the one job too wide for the register file: [20 k-blocks][64 lanes][16 B]
+  TF_LDS = TF_O_WB + 20 * 1024
 };
 static_assert(TF_A1B >= 0, "ACT1 image base");
 
@@ -66,6 +67,11 @@ struct TfArgs {
   uint32_t drop_step;
   const float* keep1;        // injected keep masks (1 keep / 0 drop) [B*L][128], [B*L][80]; null: Philox
   const float* keep2;
+  // local reparameterisation (EM_LRT; [3P] tyxe.poutine.local_reparameterization, bayesian.py:66-67): slot A = mu, slot B =
+  // sigma^2 (shared by the particles), out = loc + sqrt(var) eps with var = sigma^2 . x^2; eps from Philox or injected
+  NoiseRefs nz;
+  CallGeom cg;
+  float* q1; float* qm; float* q2;   // q = eps / (2 sd) of ACT1 / MID / ACT2 outputs (training step: the backward's d out / d var)
   int S, B, L, nsplit;
 };
 
@@ -107,15 +113,16 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __bui
 template <int EM, bool TRAIN, class J, bool DROP = false>
 struct TfJobRun {
   static constexpr int LY = J::layer, NT = J::nt;
-  static constexpr bool FO = (EM == EM_FLIPOUT);
+  static constexpr bool FO = (EM == EM_FLIPOUT), LRT = (EM == EM_LRT), TWO = FO || LRT;   // TWO: a second weight operand (dW | sigma^2)
   static constexpr int STAGE = tl_stage(LY), TAPS = tl_taps(LY), PAD = (TAPS - 1) / 2, CB = tf_cb(LY), TAIL = tf_tail(LY);
   static constexpr int NKB = TAPS * CB, NTL = TAPS * TAIL;
   static constexpr int RS = STAGE == 0 ? TF_RSX : TF_RSB;
-  f32x4 wa[NKB], wb[FO ? NKB : 1];
-  float ta[NTL ? NTL : 1], tb[(FO && NTL) ? NTL : 1];
-  f32x4 bias;
+  static constexpr bool WBL = J::wl_lds && LRT;   // the second operand's fragments live in LDS (lane-linear: conflict-free)
+  f32x4 wa[NKB], wb[(TWO && !WBL) ? NKB : 1];
+  float ta[NTL ? NTL : 1], tb[(TWO && NTL) ? NTL : 1];
+  f32x4 bias, biasv;
 
-  __device__ __forceinline__ void init(const TfArgs& A, int s, int lane) {
+  __device__ __forceinline__ void init(const TfArgs& A, char* smem, int s, int lane) {
     const int i16 = lane & 15, g4 = lane >> 4;
     const LayerDesc ly = A.layers[LY];
     const float* pa = (const float*)A.ws.a_hi + A.ws.slot_stride_a * s + ly.w_off + (long)(NT * 16 + i16) * ly.KP;
@@ -126,11 +133,12 @@ struct TfJobRun {
       for (int cb = 0; cb < CB; ++cb) {
         const int o = tap * tf_cimg(LY) + cb * 16 + g4 * 4;
         wa[tap * CB + cb] = *(const f32x4*)(pa + o);
-        if constexpr (FO) wb[tap * CB + cb] = *(const f32x4*)(pb + o);
+        if constexpr (WBL) *(f32x4*)(smem + TF_O_WB + (tap * CB + cb) * 1024 + lane * 16) = *(const f32x4*)(pb + o);
+        else if constexpr (TWO) wb[tap * CB + cb] = *(const f32x4*)(pb + o);
       }
       if constexpr (TAIL) {
         ta[tap] = pa[tap * tf_cimg(LY) + 16 + g4];
-        if constexpr (FO) tb[tap] = pb[tap * tf_cimg(LY) + 16 + g4];
+        if constexpr (TWO) tb[tap] = pb[tap * tf_cimg(LY) + 16 + g4];
       }
     }
     const int chb = NT * 16 + 4 * g4;
@@ -138,6 +146,12 @@ struct TfJobRun {
     const float* ba = A.ws.bias_a + (long)A.ws.bias_stride_a * s + ly.bias_off + chb;
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias[r] = r < nv ? ba[r] : 0.f;
+    biasv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LRT) {
+      const float* bb = A.ws.bias_b + ly.bias_off + chb;   // sigma_b^2
+#pragma unroll
+      for (int r = 0; r < 4; ++r) biasv[r] = r < nv ? bb[r] : 0.f;
+    }
   }
 
   // k = index of the window inside this workgroup's list; R0 = first row of the window in the [S*B*L] row space
@@ -156,6 +170,7 @@ struct TfJobRun {
     constexpr int chb0 = NT * 16;
     // one accumulator per m-tile: out = bias + W_mu x  (+ Flipout: (s_out o dW o s_in) x, both signs folded into the dW fragment)
     f32x4 acc[2] = {bias, bias};
+    f32x4 accv[2] = {biasv, biasv};   // LRT: var = sigma_b^2 + sigma_W^2 . x^2
     // the window's sign words of this layer, once per job: the per-k-block table index is register arithmetic, the table
     // read one LDS access (no chain of dependent LDS reads in front of a k-block's MFMAs)
     uint32_t sw[4] = {0u, 0u, 0u, 0u}, so = 0;
@@ -170,11 +185,13 @@ struct TfJobRun {
       f32x4 x[2];
       uint4 m;
       float xt[2];
+      f32x4 wbk;
     };
     auto fetch = [&](int kb, Op& o) __attribute__((always_inline)) {
       const int tap = kb / CB, cb = kb - tap * CB;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) o.x[mt] = *(const f32x4*)(lb + (mt * 16 + tap - PAD + HALO) * RS + (tf_inch(LY) + cb * 16) * 4);
+      if constexpr (WBL) o.wbk = *(const f32x4*)(smem + TF_O_WB + kb * 1024 + lane * 16);
       if constexpr (FO) {
         // s_in of the layer's own input channels cb*16 + 4 g4 .. + 3
         const uint32_t nib = (sw[(cb * 16) >> 5] >> (((cb * 16) & 31) + 4 * g4)) & 15u;
@@ -206,10 +223,23 @@ struct TfJobRun {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wbm[j], cur.x[mt][j], acc[mt]);
       }
+      if constexpr (LRT) {
+        f32x4 x2[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) x2[mt] = cur.x[mt] * cur.x[mt];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) accv[mt] = mfma4(WBL ? cur.wbk[j] : wb[WBL ? 0 : kb][j], x2[mt][j], accv[mt]);
+      }
       if constexpr (TAIL) {
         if (cb == CB - 1) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(ta[tap], cur.xt[mt], acc[mt]);
+          if constexpr (LRT) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) accv[mt] = mfma4(tb[tap], cur.xt[mt] * cur.xt[mt], accv[mt]);
+          }
           if constexpr (FO) {
             const uint32_t m = (((sw[0] >> (16 + g4)) & 1u) ^ (so >> 4)) << 31;
             const float tbm = xor1(tb[tap], m);
@@ -226,6 +256,42 @@ struct TfJobRun {
     if constexpr (TFV & 2) {
       asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
       return;
+    }
+    if constexpr (LRT) {
+      // out = loc + sqrt(var) eps, q = eps / (2 sd) kept for the backward (group_fwd_kernel's epilogue; U5 / U6: a negative
+      // variance is replaced by 1e-6).  Pad channels have loc = var = 0: out = 0 whatever eps is.
+      constexpr int OOFFq = tl_ooff(LY), OUTKq = tl_outk(LY), CTq = OUTKq == 2 ? 80 : 128;
+      const int cout = tl_cout(LY), lch0 = NT * 16 + 4 * g4;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row = mt * 16 + i16;
+        const unsigned R = R0 + (unsigned)min(row, A.L - 1);
+        f32x4 eps;
+        if (A.nz.use_philox_lrt) {
+          const long Rg = global_row(A.cg, A.L, (int)R);
+          const uint64_t idx = (uint64_t)Rg * (uint64_t)(((cout + 15) & ~15) >> 2) + (uint64_t)(lch0 >> 2);
+          eps = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)LY << 8), A.nz.step, A.nz.seed);
+        } else {
+          const float* e = A.nz.lrt_eps[LY] + (long)R * cout + lch0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) eps[r] = (lch0 + r < cout) ? e[r] : 0.f;
+        }
+        f32x4 qv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float var = accv[mt][r];
+          if (var < 0.f) var = 1e-6f;
+          const float sd = sqrtf(var);
+          acc[mt][r] = acc[mt][r] + sd * eps[r];
+          qv[r] = sd > 0.f ? eps[r] / (2.f * sd) : 0.f;
+        }
+        if constexpr (TRAIN) {
+          if (row < A.L) {
+            float* qp = OUTKq == 0 ? A.q1 : (OUTKq == 1 ? A.qm : A.q2);
+            *(f32x4*)(qp + (long)R * CTq + OOFFq + lch0) = qv;
+          }
+        }
+      }
     }
     const int chb = chb0 + 4 * g4;
     f32x4 v[2];
@@ -315,7 +381,7 @@ struct TfJobRun {
 
 template <int EM, bool TRAIN, bool DROP>
 struct TfJobRun<EM, TRAIN, TNone, DROP> {
-  __device__ __forceinline__ void init(const TfArgs&, int, int) {}
+  __device__ __forceinline__ void init(const TfArgs&, char*, int, int) {}
   __device__ __forceinline__ void run(const TfArgs&, char*, int, unsigned, int) const {}
 };
 
@@ -396,9 +462,9 @@ __device__ __forceinline__ void tf_role(const TfArgs& A, char* smem, int s, int 
   TfJobRun<EM, TRAIN, J0, DROP> r0;
   TfJobRun<EM, TRAIN, J1, DROP> r1;
   TfJobRun<EM, TRAIN, J2, DROP> r2;
-  r0.init(A, s, lane);
-  r1.init(A, s, lane);
-  r2.init(A, s, lane);
+  r0.init(A, smem, s, lane);
+  r1.init(A, smem, s, lane);
+  r2.init(A, smem, s, lane);
   TfLoader<EM == EM_FLIPOUT> ld;
   if constexpr (LOADER) {
     ld.setup(A, s, split, lane);
@@ -450,12 +516,12 @@ __global__ __launch_bounds__(TF_THREADS) void tf_fwd_kernel(const TfArgs A) {
 #define TJ(...) TJob<__VA_ARGS__>
   // MFMAs per window with Flipout (plain: half): wave w and w + 4 share SIMD w
   switch (wave) {
-    case 0: TF_ROLE(false, TJ(8, 0), TNone, TNone); break;               // k5 64->16: 320
+    case 0: TF_ROLE(EM == EM_LRT, TJ(8, 0, true), TNone, TNone); break;  // k5 64->16: 320 (LRT: its sigma^2 fragments in LDS, + the loader)
     case 4: TF_ROLE(false, TJ(5, 0), TJ(5, 1), TJ(0, 0)); break;         // 128 + 128 + 20
     case 1: TF_ROLE(false, TJ(6, 0), TJ(2, 0), TNone); break;            // 192 + 100
     case 5: TF_ROLE(false, TJ(5, 2), TJ(5, 3), TJ(1, 0)); break;         // 128 + 128 + 60
     case 2: TF_ROLE(false, TJ(7, 0), TJ(7, 1), TJ(1, 1)); break;         // 128 + 128 + 60
-    case 6: TF_ROLE(true, TJ(7, 2), TJ(7, 3), TJ(0, 1)); break;          // 128 + 128 + 20, + the loader
+    case 6: TF_ROLE(EM != EM_LRT, TJ(7, 2), TJ(7, 3), TJ(0, 1)); break;  // 128 + 128 + 20, + the loader (Flipout / plain)
     case 3: TF_ROLE(false, TJ(9, 0), TJ(9, 1), TJ(3, 0)); break;         // 128 + 128 + 60
     default: TF_ROLE(false, TJ(4, 0), TJ(2, 1), TJ(3, 1)); break;        // 128 + 100 + 60
   }

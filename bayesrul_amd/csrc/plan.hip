@@ -1843,9 +1843,12 @@ static int check_dropout(const BnnPlan* p, const Ctx* c);
 
 // fused fp32 conv trunk (kernels_f32.h): groups 0..2 of the Inception net in one launch, exact fp32 MFMA
 static bool tf_ok(const BnnPlan* p, const Ctx* c) {
-  return p->d.prec == BNN_PREC_F32 && p->d.net == BNN_NET_INCEPTION && c->em != EM_LRT && p->d.win_length <= 30 &&
-         p->d.n_features == 18;
+  return p->d.prec == BNN_PREC_F32 && p->d.net == BNN_NET_INCEPTION && p->d.win_length <= 30 && p->d.n_features == 18;
 }
+// which parts of the fused fp32 path exist for the call's estimator (LRT: built stage by stage; the generic per-group
+// kernels take over where a stage is missing - they share the tensors' layout)
+static bool tf_bwd_ok(const BnnPlan* p, const Ctx* c) { return tf_ok(p, c) && c->em != EM_LRT; }
+static bool tf_dense_ok(const BnnPlan* p, const Ctx* c) { return tf_ok(p, c) && c->em != EM_LRT; }
 
 static int tf_check_tables(const BnnPlan* p) {
   for (int l = 0; l < 10; ++l) {
@@ -1885,6 +1888,11 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
   T.m_act1 = c->train ? (unsigned char*)p->bufs.workspace + p->o_mact1 : nullptr;
   T.m_mid = c->train ? (unsigned char*)p->bufs.workspace + p->o_mmid : nullptr;
   T.m_act2 = c->train ? (unsigned char*)p->bufs.workspace + p->o_mact2 : nullptr;
+  T.nz = c->nz;
+  T.cg = G.cg;
+  T.q1 = c->train ? tens_ptr(p, TI_ACT1, 2) : nullptr;
+  T.qm = c->train ? tens_ptr(p, TI_MID, 2) : nullptr;
+  T.q2 = c->train ? tens_ptr(p, TI_ACT2, 2) : nullptr;
   T.S = c->S;
   T.B = c->B;
   T.L = L;
@@ -1917,6 +1925,8 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
     }
   } else if (c->em == EM_FLIPOUT) {
     if (c->train) LAUNCH_TF(EM_FLIPOUT, true); else LAUNCH_TF(EM_FLIPOUT, false);
+  } else if (c->em == EM_LRT) {
+    if (c->train) LAUNCH_TF(EM_LRT, true); else LAUNCH_TF(EM_LRT, false);
   } else {
     if (c->train) LAUNCH_TF(EM_PLAIN, true); else LAUNCH_TF(EM_PLAIN, false);
   }
@@ -2076,7 +2086,7 @@ static int launch_tf_dw(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int kind
 
 // the wide dense layer of the Inception net on the fp32 plan: K-split, weight-stationary (kernels_f32.h)
 static bool densef_ok(const BnnPlan* p, const Ctx* c, const GroupArgs& A) {
-  if (!tf_ok(p, c) || p->o_dks == 0 || !A.g.is_dense || A.g.n_branch != 1 || A.g.in_bcast) return false;
+  if (!tf_dense_ok(p, c) || p->o_dks == 0 || !A.g.is_dense || A.g.n_branch != 1 || A.g.in_bcast) return false;
   const BranchDesc& br = A.g.br[0];
   const LayerDesc& ly = p->layers[br.layer];
   return br.cout == 64 && br.n_off == 0 && br.in_off == 0 && br.out_off == 0 && br.cin_p == ly.cin && ly.cin % FDF_CH == 0 &&
@@ -2371,9 +2381,9 @@ static int zero_grad_images(BnnPlan* p, const Ctx* c) {
 // conv layers, one workgroup per (particle, chunk) for the wide dense layer), the fill is not needed at all: the fin
 // kernel of the forward zeroed the last layer's few elements.
 static int prepare_fused_tail(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
-  c->last_fused = (trunk_ok(p, c) || tf_ok(p, c)) && p->fwd_fused_last && last_fused_ok(p, c->em, p->n_groups - 2);
+  c->last_fused = (trunk_ok(p, c) || (tf_bwd_ok(p, c) && tf_dense_ok(p, c))) && p->fwd_fused_last && last_fused_ok(p, c->em, p->n_groups - 2);
   if (!c->last_fused) return 0;
-  if (tf_ok(p, c)) {
+  if (tf_bwd_ok(p, c) && tf_dense_ok(p, c)) {
     // fp32 plan: every gradient element of the conv layers (slab reduction) and of the wide dense layer (densef_dw_kernel,
     // dense_add2_kernel) is STORED; the last layer's few elements, which the head launch adds to, were zeroed by the fin
     // kernel of the forward: no fill
@@ -2395,7 +2405,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   for (int gi = p->n_groups - 1 - (c->last_fused ? 1 : 0); gi >= 0; --gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
-    if (!A.g.is_dense && tf_ok(p, c)) {
+    if (!A.g.is_dense && tf_bwd_ok(p, c)) {
       // fp32 conv trunk: dz of MID / ACT1 (and the masked dz of ACT2), then the two dW launches and the slab reduction
       if (gi == 2) {
         BNN_TRY(launch_tf_dx(p, a, c, act2_premasked));
