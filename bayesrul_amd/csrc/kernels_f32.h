@@ -1349,6 +1349,7 @@ struct DfArgs {
   const uint32_t* sg_in; const uint32_t* sg_out;   // packed signs of the layer [S*B][siw] / [S*B][sow]
   int siw, sow;
   float* slab;                        // [nchunk][S*B][64] partial pre-activations
+  float* slabv;                       // LRT: partial variances sigma^2 . x^2 (same layout)
   long slab_stride;
   int S, B, nchunk, nrs, rows_per_wg;
 };
@@ -1356,7 +1357,7 @@ struct DfArgs {
 template <int EM>
 __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool FO = (EM == EM_FLIPOUT);
+  constexpr bool FO = (EM == EM_FLIPOUT), LRT = (EM == EM_LRT), TWO = FO || LRT;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = wave & 3, mh = wave >> 2;
@@ -1371,14 +1372,14 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
   const int w0 = ch0 >> 5;   // first s_in word of the chunk
   build_sign_lut_f32((uint4*)(smem + FDF_O_LUT), tid);
   // ---- weight fragments: rows nt*16 + i16 of the forward image, k-blocks of the chunk ----
-  f32x4 wa[FDF_KB], wb[FO ? FDF_KB : 1];
+  f32x4 wa[FDF_KB], wb[TWO ? FDF_KB : 1];
   {
     const float* pa = A.wa + A.stride_a * s + (long)(nt * 16 + i16) * A.KP + ch0 + 4 * g4;
     const float* pb = A.wb + A.stride_b * s + (long)(nt * 16 + i16) * A.KP + ch0 + 4 * g4;
 #pragma unroll
     for (int kb = 0; kb < FDF_KB; ++kb) {
       wa[kb] = *(const f32x4*)(pa + kb * 16);
-      if constexpr (FO) wb[kb] = *(const f32x4*)(pb + kb * 16);
+      if constexpr (TWO) wb[kb] = *(const f32x4*)(pb + kb * 16);
     }
   }
   // ---- staging plan: 4 chunks of the step's [32][240] rows per thread, sign words by the first 352 threads ----
@@ -1458,10 +1459,11 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
       __builtin_amdgcn_sched_barrier(0);
       f32x4 xs = cur.x;
       if constexpr (FO) xs = xor4(cur.x, cur.m);
+      if constexpr (LRT) xs = cur.x * cur.x;   // var = sigma^2 . x^2
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         accm = mfma4(wa[kb][j], cur.x[j], accm);
-        if constexpr (FO) accp = mfma4(wb[kb][j], xs[j], accp);
+        if constexpr (TWO) accp = mfma4(wb[kb][j], xs[j], accp);
       }
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
@@ -1479,7 +1481,10 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] += ps[r];
     }
-    if (b < b1) *(f32x4*)(A.slab + chunk * A.slab_stride + ((long)s * A.B + b) * 64 + nt * 16 + 4 * g4) = v;
+    if (b < b1) {
+      *(f32x4*)(A.slab + chunk * A.slab_stride + ((long)s * A.B + b) * 64 + nt * 16 + 4 * g4) = v;
+      if constexpr (LRT) *(f32x4*)(A.slabv + chunk * A.slab_stride + ((long)s * A.B + b) * 64 + nt * 16 + 4 * g4) = accp;
+    }
     lds_barrier();
   }
 }
@@ -1505,6 +1510,8 @@ struct DfBwdArgs {
   float x_scale, h_scale;               // MC-dropout: 1 / (1 - p/4) on dX, 1 / (1 - p) on dz = dH [H > 0]; else 1
   float* gw_a; float* gw_b; float* gb_a;   // per-particle gradient images of the layer (forward layout [64][KP]) / bias gradients
   float* gw2_a; float* gw2_b; float* gb2_a;   // the second row range's partial images (same strides; summed by dense_add2_kernel)
+  const float* qh;                      // LRT: q = eps / (2 sd) of the layer's output [S*B][64]: dVar = dz q
+  float* gb_b; float* gb2_b;            // LRT: gradient of sigma_b^2 (+ its second-range partial)
   long gw_stride; int gb_stride;
   int KP;
   int S, B, nchunk, nrs, rows_per_wg;
@@ -1523,30 +1530,37 @@ enum {
   DWF_LDS = 2 * DWF_SLOT
 };
 
-// dz = dH [H > 0] of 4 couts of one row (+ its s_out copy): the staging unit of both backward kernels
+// dz = dH [H > 0] of 4 couts of one row, and the second product's operand (Flipout: dz o s_out; LRT: dVar = dz q): the
+// staging unit of both backward kernels
 struct DzStage {
-  tf_u32x4 g, y;
+  tf_u32x4 g, y, qv;
   uint32_t so;
   int row, c4;
   __device__ __forceinline__ void setup(int tid) { row = tid >> 4; c4 = tid & 15; }
-  template <bool FO>
+  template <int EM>
   __device__ __forceinline__ void fetch(const DfBwdArgs& A, int s, int bb) {
     const long R = (long)s * A.B + min(bb + row, A.B - 1);
     g = *(const tf_u32x4*)(A.dh + R * 64 + c4 * 4);
     y = *(const tf_u32x4*)(A.h + R * 64 + c4 * 4);
-    if constexpr (FO) so = A.sg_out[R * A.sow + (c4 >> 3)];
+    if constexpr (EM == EM_FLIPOUT) so = A.sg_out[R * A.sow + (c4 >> 3)];
+    if constexpr (EM == EM_LRT) qv = *(const tf_u32x4*)(A.qh + R * 64 + c4 * 4);
   }
-  template <bool FO>
+  template <int EM>
   __device__ __forceinline__ void put(char* dz, char* dzs, int pitch, bool live, float hs) const {
     tf_u32x4 d = g;
     const f32x4 yy = __builtin_bit_cast(f32x4, y);
 #pragma unroll
     for (int e = 0; e < 4; ++e) d[e] = (live && yy[e] > 0.f) ? __float_as_uint(__uint_as_float(d[e]) * hs) : 0u;
     *(tf_u32x4*)(dz + row * pitch + c4 * 16) = d;
-    if constexpr (FO) {
+    if constexpr (EM == EM_FLIPOUT) {
       const uint32_t nib = (so >> ((c4 & 7) * 4)) & 15u;
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] ^= ((nib >> e) & 1u) << 31;
+      *(tf_u32x4*)(dzs + row * pitch + c4 * 16) = d;
+    }
+    if constexpr (EM == EM_LRT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = __float_as_uint(__uint_as_float(d[e]) * __uint_as_float(qv[e]));
       *(tf_u32x4*)(dzs + row * pitch + c4 * 16) = d;
     }
   }
@@ -1555,7 +1569,7 @@ struct DzStage {
 template <int EM>
 __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool FO = (EM == EM_FLIPOUT);
+  constexpr bool FO = (EM == EM_FLIPOUT), LRT = (EM == EM_LRT), TWO = FO || LRT;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c0t = wave & 3, mh = wave >> 2;   // c-tiles c0t, c0t + 4, c0t + 8, c0t + 12 (< 15); row half
@@ -1568,7 +1582,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
   const int nsteps = (b1 - b0 + FDF_ROWS - 1) / FDF_ROWS;
   const int ch0 = chunk * FDF_CH, w0 = ch0 >> 5;
   build_sign_lut_f32((uint4*)(smem + FDX_O_LUT), tid);
-  f32x4 wa[4][4], wb[FO ? 4 : 1][4];
+  f32x4 wa[4][4], wb[TWO ? 4 : 1][4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int ct = min(c0t + 4 * m, FDF_KB - 1);
@@ -1576,7 +1590,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       wa[m][kb] = *(const f32x4*)(A.wat + A.stride_at * s + ro + kb * 16);
-      if constexpr (FO) wb[m][kb] = *(const f32x4*)(A.wbt + A.stride_bt * s + ro + kb * 16);
+      if constexpr (TWO) wb[m][kb] = *(const f32x4*)(A.wbt + A.stride_bt * s + ro + kb * 16);
     }
   }
   DzStage zs;
@@ -1586,14 +1600,14 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
   uint32_t sw = 0;
   auto fetch = [&](int t) __attribute__((always_inline)) {
     const int bb = b0 + t * FDF_ROWS;
-    zs.fetch<FO>(A, s, bb);
+    zs.fetch<EM>(A, s, bb);
     if constexpr (FO) {
       if (sq_on) sw = A.sg_in[((long)s * A.B + min(bb + sq_row, A.B - 1)) * A.siw + min(w0 + sq_w, A.siw - 1)];
     }
   };
   auto put = [&](int t) __attribute__((always_inline)) {
     char* sl = smem + (t % FDF_NSLOT) * FDX_SLOT;
-    zs.put<FO>(sl, sl + FDX_O_DZS, FDX_RSZ, b0 + t * FDF_ROWS + zs.row < b1, A.h_scale);
+    zs.put<EM>(sl, sl + FDX_O_DZS, FDX_RSZ, b0 + t * FDF_ROWS + zs.row < b1, A.h_scale);
     if constexpr (FO) {
       if (sq_on) ((uint32_t*)(sl + FDX_O_SG))[sq_row * FDF_SGW + sq_w] = sw;
     }
@@ -1614,27 +1628,40 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
       for (int m = 0; m < 4; ++m)
         mxb[m] = A.m_x[R * (A.x_ctot >> 2) + ((ch0 + min(c0t + 4 * m, FDF_KB - 1) * 16) >> 2) + g4];
     }
-    f32x4 accm[4], accp[FO ? 4 : 1];
+    f32x4 accm[4], accp[TWO ? 4 : 1];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       accm[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (FO) accp[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (TWO) accp[m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // LRT: dX = mu^T dLoc + 2 X o (sigma^2^T dVar): the layer's input values of this lane's outputs, fetched ahead of the MFMAs
+    f32x4 xv[LRT ? 4 : 1];
+    if constexpr (LRT) {
+      const long R = (long)s * A.B + min(b0 + t * FDF_ROWS + mh * 16 + i16, A.B - 1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) xv[m] = *(const f32x4*)(A.x + R * A.x_ctot + ch0 + min(c0t + 4 * m, FDF_KB - 1) * 16 + 4 * g4);
+    }
+    // all operand reads of the step first (K = 64 couts: four k-blocks), then its MFMAs
+    f32x4 z[4], zz[TWO ? 4 : 1];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      const f32x4 z = *(const f32x4*)(lb + kb * 64);
-      f32x4 zz = z;
-      if constexpr (FO) zz = *(const f32x4*)(lb + FDX_O_DZS + kb * 64);
+      z[kb] = *(const f32x4*)(lb + kb * 64);
+      if constexpr (TWO) zz[kb] = *(const f32x4*)(lb + FDX_O_DZS + kb * 64);   // Flipout: dz o s_out; LRT: dVar = dz q
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          if (c0t + 4 * m < FDF_KB) {
-            accm[m] = mfma4(wa[m][kb][j], z[j], accm[m]);
-            if constexpr (FO) accp[m] = mfma4(wb[m][kb][j], zz[j], accp[m]);
+          if (m < 3 || c0t + 4 * m < FDF_KB) {
+            accm[m] = mfma4(wa[m][kb][j], z[kb][j], accm[m]);
+            if constexpr (TWO) accp[m] = mfma4(wb[m][kb][j], zz[kb][j], accp[m]);
           }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < nsteps) put(t + 1);
     if (t + 2 < nsteps) fetch(t + 2);
     const int b = b0 + t * FDF_ROWS + mh * 16 + i16;
@@ -1651,6 +1678,10 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += ps[r];
         }
+        if constexpr (LRT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += 2.f * xv[m][r] * accp[m][r];
+        }
         if (A.m_x) v = mask4(v, mxb[m]) * A.x_scale;   // the layer's input is a ReLU output: its gradient is wanted where it is positive only
         if (b < b1) *(f32x4*)(A.dx + ((long)s * A.B + b) * A.x_ctot + c) = v;
       }
@@ -1662,7 +1693,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
 template <int EM>
 __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool FO = (EM == EM_FLIPOUT);
+  constexpr bool FO = (EM == EM_FLIPOUT), LRT = (EM == EM_LRT), TWO = FO || LRT;
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = wave & 3, cpar = wave >> 2;   // c-tiles cpar, cpar + 2, ... (< 15)
@@ -1678,13 +1709,13 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
     uint32_t* z = (uint32_t*)smem;
     for (int k = tid; k < DWF_LDS / 4; k += TF_THREADS) z[k] = 0u;
   }
-  f32x4 acc_a[8], acc_b[FO ? 8 : 1];
+  f32x4 acc_a[8], acc_b[TWO ? 8 : 1];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     acc_a[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (FO) acc_b[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (TWO) acc_b[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  float bsum = 0.f;
+  float bsum = 0.f, bsumv = 0.f;
   // staging: X chunk [32][240] (4 chunks per thread), dz, sign words
   int xq_row[4], xq_off[4], xq_dst[4];
 #pragma unroll
@@ -1708,7 +1739,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
       const long R = (long)s * A.B + min(bb + max(xq_row[j], 0), A.B - 1);
       xr[j] = *(const tf_u32x4*)((const char*)A.x + R * A.x_ctot * 4 + xq_off[j]);
     }
-    zs.fetch<FO>(A, s, bb);
+    zs.fetch<EM>(A, s, bb);
     if constexpr (FO) {
       if (sq_on) sw = A.sg_in[((long)s * A.B + min(bb + sq_row, A.B - 1)) * A.siw + min(w0 + sq_w, A.siw - 1)];
     }
@@ -1719,7 +1750,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
     for (int j = 0; j < 4; ++j)
       if (xq_row[j] >= 0) *(tf_u32x4*)(sl + xq_dst[j]) = xr[j];
     // rows past the end of the range carry dz = 0: their X rows (clamped copies) do not contribute
-    zs.put<FO>(sl + DWF_O_DZ, sl + DWF_O_DZS, DWF_RSZ, b0 + t * FDF_ROWS + zs.row < b1, A.h_scale);
+    zs.put<EM>(sl + DWF_O_DZ, sl + DWF_O_DZS, DWF_RSZ, b0 + t * FDF_ROWS + zs.row < b1, A.h_scale);
     if constexpr (FO) {
       if (sq_on) ((uint32_t*)(sl + DWF_O_SG))[sq_row * FDF_SGW + sq_w] = sw;
     }
@@ -1735,15 +1766,19 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
     if (t + 1 < nsteps) put(t + 1);
     if (t + 2 < nsteps) fetch(t + 2);
     const char* zi = sl + DWF_O_DZ + g4 * DWF_RSZ + (nt * 16 + i16) * 4;
-    float bz[8], bzs[FO ? 8 : 1];
+    float bz[8], bzs[TWO ? 8 : 1];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       bz[ks] = *(const float*)(zi + 4 * ks * DWF_RSZ);
-      if constexpr (FO) bzs[ks] = *(const float*)(zi + (DWF_O_DZS - DWF_O_DZ) + 4 * ks * DWF_RSZ);
+      if constexpr (TWO) bzs[ks] = *(const float*)(zi + (DWF_O_DZS - DWF_O_DZ) + 4 * ks * DWF_RSZ);
     }
     if (chunk == 0 && cpar == 0) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) bsum += bz[ks];
+      if constexpr (LRT) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) bsumv += bzs[ks];
+      }
     }
     const uint32_t* sgl = (const uint32_t*)(sl + DWF_O_SG) + g4 * FDF_SGW;
     // tile m = c-tile cpar + 2 m (tile 7 exists for cpar = 0 only); the column reads (and sign words) of tile m + 1 are
@@ -1777,6 +1812,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
             const uint32_t bit = (cur.sw[ks] >> (c & 31)) & 1u;
             acc_b[m] = mfma4(xor1(cur.ax[ks], bit << 31), bzs[ks], acc_b[m]);
           }
+          if constexpr (LRT) acc_b[m] = mfma4(cur.ax[ks] * cur.ax[ks], bzs[ks], acc_b[m]);   // d sigma^2 = dVar^T x^2
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1795,7 +1831,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
     const int ct = cpar + 2 * m;
     if (ct < FDF_KB) {
       *(f32x4*)(gwa + ct * 16) = acc_a[m];
-      if constexpr (FO) *(f32x4*)(gwb + ct * 16) = acc_b[m];
+      if constexpr (TWO) *(f32x4*)(gwb + ct * 16) = acc_b[m];
     }
   }
   if (chunk == 0 && cpar == 0) {
@@ -1803,6 +1839,12 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
     t += __shfl_xor(t, 16, 64);
     t += __shfl_xor(t, 32, 64);
     if (g4 == 0) (rs == 0 ? A.gb_a : A.gb2_a)[(long)A.gb_stride * s + n] = t;
+    if constexpr (LRT) {
+      float tv = bsumv;
+      tv += __shfl_xor(tv, 16, 64);
+      tv += __shfl_xor(tv, 32, 64);
+      if (g4 == 0) (rs == 0 ? A.gb_b : A.gb2_b)[(long)A.gb_stride * s + n] = tv;
+    }
   }
 }
 
@@ -1849,11 +1891,18 @@ struct DenseFinF32Args {
   float* g2_a; float* g2_b; float* g2_ba;
   long g2_stride; int g2_bstride;
   int S;
+  // LRT (EM_LRT): partial variances, sigma_b^2 of both layers, the output noise and where q = eps / (2 sd) goes
+  const float* slabv;
+  const float* biasv; const float* b2v;   // [bias_total] arrays offset to the two layers (shared by the particles)
+  NoiseRefs nz; CallGeom cg;
+  int layer1, layer2;                     // layer ids (noise streams)
+  float* qh; float* qz;                   // [rows][64], [rows][2] (training step; null otherwise)
+  float* g2_bb;                           // the last layer's sigma_b^2 gradient elements (zeroed with the others)
 };
 
 template <int EM>
 __global__ __launch_bounds__(256) void densef_fin_kernel(const DenseFinF32Args F) {
-  constexpr bool FO = (EM == EM_FLIPOUT);
+  constexpr bool FO = (EM == EM_FLIPOUT), LRT = (EM == EM_LRT);
   const int t = blockIdx.x * 256 + threadIdx.x;
   const int row = min(t >> 4, F.rows - 1), ch = (t & 15) * 4;   // surplus threads redo the last row (the shuffles need full groups)
   const bool live = (t >> 4) < F.rows;
@@ -1864,6 +1913,35 @@ __global__ __launch_bounds__(256) void densef_fin_kernel(const DenseFinF32Args F
     const f32x4 a = *(const f32x4*)(p + c * F.slab_stride);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += a[r];
+  }
+  long Rg = 0;
+  if constexpr (LRT) {
+    // hidden layer: out = loc + sqrt(var) eps (group_fwd_kernel's epilogue), q for the backward
+    f32x4 var = *(const f32x4*)(F.biasv + ch);
+    const float* pv = F.slabv + (long)row * 64 + ch;
+    for (int c = 0; c < F.nchunk; ++c) {
+      const f32x4 a = *(const f32x4*)(pv + c * F.slab_stride);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) var[r] += a[r];
+    }
+    Rg = global_row(F.cg, 1, row);
+    f32x4 eps;
+    if (F.nz.use_philox_lrt) {
+      const uint64_t idx = (uint64_t)Rg * 16ull + (uint64_t)(ch >> 2);   // cout_p16 / 4 = 16 quads per row
+      eps = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)F.layer1 << 8), F.nz.step, F.nz.seed);
+    } else {
+      eps = *(const f32x4*)(F.nz.lrt_eps[F.layer1] + (long)row * 64 + ch);
+    }
+    f32x4 qv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float vv = var[r];
+      if (vv < 0.f) vv = 1e-6f;
+      const float sd = sqrtf(vv);
+      v[r] += sd * eps[r];
+      qv[r] = sd > 0.f ? eps[r] / (2.f * sd) : 0.f;
+    }
+    if (live && F.qh) *(f32x4*)(F.qh + (long)row * 64 + ch) = qv;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -1878,6 +1956,7 @@ __global__ __launch_bounds__(256) void densef_fin_kernel(const DenseFinF32Args F
     F.g2_a[F.g2_stride * zs + ze] = 0.f;
     F.g2_b[F.g2_stride * zs + ze] = 0.f;
     if (ze < 2) F.g2_ba[(long)F.g2_bstride * zs + ze] = 0.f;
+    if (LRT && ze < 2) F.g2_bb[(long)F.g2_bstride * zs + ze] = 0.f;
   }
   float m[2] = {0.f, 0.f}, pz[2] = {0.f, 0.f};
   uint32_t bits = 0;
@@ -1893,22 +1972,44 @@ __global__ __launch_bounds__(256) void densef_fin_kernel(const DenseFinF32Args F
 #pragma unroll
       for (int r = 0; r < 4; ++r) pz[k] += (((bits >> r) & 1u) ? -v[r] : v[r]) * wb[r];
     }
+    if constexpr (LRT) {   // var_k = sum_c h_c^2 sigma^2[k][c]
+      const f32x4 wb = *(const f32x4*)(F.w2b + F.w2_stride_b * s + wo);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pz[k] += v[r] * v[r] * wb[r];
+    }
   }
 #pragma unroll
   for (int d = 8; d >= 1; d >>= 1) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       m[k] += __shfl_xor(m[k], d, 16);
-      if constexpr (FO) pz[k] += __shfl_xor(pz[k], d, 16);
+      if constexpr (FO || LRT) pz[k] += __shfl_xor(pz[k], d, 16);
     }
   }
   if (live && (t & 15) == 0) {
     uint32_t so = 0;
     if constexpr (FO) so = F.sg_out[(long)row * F.sow];
+    f32x4 eps2 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (LRT) {
+      if (F.nz.use_philox_lrt) {
+        const uint64_t idx = (uint64_t)Rg * 4ull;   // cout_p16 / 4 = 4 quads per row, couts 0, 1 in quad 0
+        eps2 = philox_normal4((uint32_t)idx, (uint32_t)(idx >> 32), NK_LRT | ((uint32_t)F.layer2 << 8), F.nz.step, F.nz.seed);
+      } else {
+        eps2[0] = F.nz.lrt_eps[F.layer2][(long)row * 2];
+        eps2[1] = F.nz.lrt_eps[F.layer2][(long)row * 2 + 1];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       float zk = m[k] + F.b2[(long)F.bias_stride * s + k];
       if constexpr (FO) zk += ((so >> k) & 1u) ? -pz[k] : pz[k];
+      if constexpr (LRT) {
+        float vv = pz[k] + F.b2v[k];
+        if (vv < 0.f) vv = 1e-6f;
+        const float sd = sqrtf(vv);
+        zk += sd * eps2[k];
+        if (F.qz) F.qz[(long)row * 2 + k] = sd > 0.f ? eps2[k] / (2.f * sd) : 0.f;
+      }
       F.z[(long)row * 2 + k] = zk;
     }
   }
@@ -1931,11 +2032,13 @@ struct HeadLastF32Args {
   int siw, sow;
   float* gw_a; float* gw_b; float* gb_a;   // offset to the layer; per particle strides below
   long gw_stride; int gb_stride;
+  const float* qz;                         // LRT: q of the net outputs [S*B][2]; dVar = dz q
+  float* gb_b;                             // LRT: gradient of sigma_b^2
 };
 
 template <int EM>
 __global__ __launch_bounds__(256) void headf_last_kernel(const HeadLastF32Args A) {
-  constexpr bool FO = (EM == EM_FLIPOUT);
+  constexpr bool FO = (EM == EM_FLIPOUT), LRT = (EM == EM_LRT), TWO = FO || LRT;
   const int tid = threadIdx.x;
   const int blk0 = blockIdx.x * HL_ROWS;
   const int idx = blk0 + tid;   // rows: threads 0 .. HL_ROWS-1
@@ -1946,7 +2049,7 @@ __global__ __launch_bounds__(256) void headf_last_kernel(const HeadLastF32Args A
   {
     const int kk = tid >> 6, c = tid & 63;
     const float* src = (kk < 2 ? A.wa + A.stride_a * s : A.wb + A.stride_b * s) + (long)(kk & 1) * A.KP + c;
-    wsh[kk][c] = (kk < 2 || FO) ? *src : 0.f;
+    wsh[kk][c] = (kk < 2 || TWO) ? *src : 0.f;
   }
   __syncthreads();
   if (tid < HL_ROWS) {
@@ -1958,7 +2061,11 @@ __global__ __launch_bounds__(256) void headf_last_kernel(const HeadLastF32Args A
     const long r = (long)s * B + min(idx, B - 1);
     uint32_t so = 0;
     if constexpr (FO) so = A.sg_out[r * A.sow];
-    const float h0 = (so & 1u) ? -g0 : g0, h1 = (so & 2u) ? -g1 : g1;   // dz o s_out
+    float h0 = (so & 1u) ? -g0 : g0, h1 = (so & 2u) ? -g1 : g1;   // dz o s_out
+    if constexpr (LRT) {   // dVar = dz q
+      h0 = g0 * A.qz[r * 2];
+      h1 = g1 * A.qz[r * 2 + 1];
+    }
     dzs[0][tid] = g0;
     dzs[1][tid] = g1;
     dzs[2][tid] = h0;
@@ -1976,6 +2083,7 @@ __global__ __launch_bounds__(256) void headf_last_kernel(const HeadLastF32Args A
         for (int q = 0; q < 4; ++q) {
           const int c = c4 * 4 + q;
           d[q] = g0 * wsh[0][c] + g1 * wsh[1][c];
+          if constexpr (LRT) d[q] += 2.f * A.h[r * 64 + c] * (h0 * wsh[2][c] + h1 * wsh[3][c]);   // + 2 h o (sigma^2^T dVar)
           if constexpr (FO) {
             const float pp = h0 * wsh[2][c] + h1 * wsh[3][c];
             d[q] += ((si[c >> 5] >> (c & 31)) & 1u) ? -pp : pp;
@@ -1989,7 +2097,7 @@ __global__ __launch_bounds__(256) void headf_last_kernel(const HeadLastF32Args A
   // ---- weight / bias gradient sums of this workgroup's rows: thread = (kind kk, channel c) ----
   const int kk = tid >> 6, c = tid & 63;   // kk 0, 1: d/dW_a rows 0, 1; kk 2, 3: d/dW_b rows 0, 1 (Flipout)
   const int nrow = min(HL_ROWS, B - blk0);
-  if (kk < 2 || FO) {
+  if (kk < 2 || TWO) {
     float acc = 0.f;
     const float* hp = A.h + ((long)s * B + blk0) * 64 + c;
     const uint32_t* sp = A.sg_in + ((long)s * B + blk0) * A.siw + (c >> 5);
@@ -2006,6 +2114,7 @@ __global__ __launch_bounds__(256) void headf_last_kernel(const HeadLastF32Args A
       for (int j = 0; j < 16; ++j) {
         float h = hv[j];
         if ((sw[j] >> (c & 31)) & 1u) h = -h;
+        if (LRT && kk >= 2) h = h * h;   // d sigma^2 = dVar^T h^2
         if (r0 + j < nrow) acc += dzs[kk][r0 + j] * h;
       }
     }
@@ -2016,5 +2125,10 @@ __global__ __launch_bounds__(256) void headf_last_kernel(const HeadLastF32Args A
     float acc = 0.f;
     for (int rr = 0; rr < nrow; ++rr) acc += dzs[tid][rr];
     atomicAdd(A.gb_a + (long)A.gb_stride * s + tid, acc);
+  }
+  if (LRT && tid >= 2 && tid < 4) {   // gradient of sigma_b^2: sum of dVar
+    float acc = 0.f;
+    for (int rr = 0; rr < nrow; ++rr) acc += dzs[tid][rr];
+    atomicAdd(A.gb_b + (long)A.gb_stride * s + (tid - 2), acc);
   }
 }

@@ -135,7 +135,8 @@ struct BnnPlan {
   // workspace layout (byte offsets)
   size_t ws_bytes = 0;
   size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
-  size_t o_dw2_a = 0, o_dw2_b = 0, o_dw2_ba = 0;   // fp32 plan: second partial images of the wide dense layer's dW
+  size_t o_dw2_a = 0, o_dw2_b = 0, o_dw2_ba = 0, o_dw2_bb = 0;   // fp32 plan: second partial images of the wide dense layer's dW
+  size_t o_dksv = 0;                               // fp32 LRT plan: partial variances of the K-split dense forward
   size_t o_mact2 = 0;                              // fp32 plan: nibble masks [ACT2 > 0] ([rows][20 B])
   size_t o_mact1 = 0, o_mmid = 0;                  // bit masks [ACT1 > 0] / [MID > 0] of the trunk kernels: [rows][16 B]
   size_t o_dks = 0;                                // partial pre-activations of the K-split dense forward [chunk][rows][64]
@@ -438,8 +439,10 @@ static void layout_workspace(BnnPlan* p) {
     p->o_dw2_a = take((size_t)S * p->img_total * 4);
     p->o_dw2_b = take((size_t)S * p->img_total * 4);
     p->o_dw2_ba = take((size_t)S * p->bias_total * 4);
+    p->o_dw2_bb = take((size_t)S * p->bias_total * 4);
     p->dks_rows = cap;
     p->o_dks = take((size_t)(p->layers[10].cin / FDF_CH) * cap * 64 * 4);   // partial pre-activations of densef_fwd_kernel
+    p->o_dksv = p->d.mode == BNN_MODE_LRT ? take((size_t)(p->layers[10].cin / FDF_CH) * cap * 64 * 4) : 0;   // LRT: partial variances
   }
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
     p->o_mact1 = take((size_t)cap * p->d.win_length * 16);
@@ -1408,8 +1411,8 @@ static bool dense_ks_ok(const BnnPlan* p, const GroupArgs& A, int em) {
 }
 
 // the last layer Linear(64, 2) of the Inception net can ride on the K-split dense kernels' fin / head launches
-static bool last_fused_ok(const BnnPlan* p, int em, int gi) {
-  if (em == EM_LRT || p->o_dks == 0 || gi + 2 != p->n_groups) return false;
+static bool last_fused_ok(const BnnPlan* p, int em, int gi, bool allow_lrt = false) {
+  if ((em == EM_LRT && !allow_lrt) || p->o_dks == 0 || gi + 2 != p->n_groups) return false;
   const GroupDesc& g = p->groups[gi + 1];
   const BranchDesc& br = g.br[0];
   const LayerDesc& ly = p->layers[br.layer];
@@ -1848,7 +1851,7 @@ static bool tf_ok(const BnnPlan* p, const Ctx* c) {
 // which parts of the fused fp32 path exist for the call's estimator (LRT: built stage by stage; the generic per-group
 // kernels take over where a stage is missing - they share the tensors' layout)
 static bool tf_bwd_ok(const BnnPlan* p, const Ctx* c) { return tf_ok(p, c) && c->em != EM_LRT; }
-static bool tf_dense_ok(const BnnPlan* p, const Ctx* c) { return tf_ok(p, c) && c->em != EM_LRT; }
+static bool tf_dense_ok(const BnnPlan* p, const Ctx* c, bool bwd = true) { (void)bwd; return tf_ok(p, c); }
 
 static int tf_check_tables(const BnnPlan* p) {
   for (int l = 0; l < 10; ++l) {
@@ -1935,8 +1938,8 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
   return 0;
 }
 
-static bool densef_ok(const BnnPlan* p, const Ctx* c, const GroupArgs& A);
-static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last, const BnnDropout* drop);
+static bool densef_ok(const BnnPlan* p, const Ctx* c, const GroupArgs& A, bool bwd);
+static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last, const BnnDropout* drop, bool train);
 
 static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const float* x) {
   const bool bf = p->d.prec == BNN_PREC_BF16X3;
@@ -1964,9 +1967,9 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
   for (int gi = trunk ? 3 : 0; gi < p->n_groups; ++gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, x, &A);
-    if (!bf && densef_ok(p, c, A)) {
-      const bool fl = last_fused_ok(p, c->em, gi);
-      BNN_TRY(launch_densef_fwd(p, A, c->em, c->st, &p->prof, gi, fl, drop_on(c) ? c->drop : nullptr));
+    if (!bf && densef_ok(p, c, A, false)) {
+      const bool fl = last_fused_ok(p, c->em, gi, true);   // the fp32 fin kernel evaluates the last layer under LRT too
+      BNN_TRY(launch_densef_fwd(p, A, c->em, c->st, &p->prof, gi, fl, drop_on(c) ? c->drop : nullptr, c->train));
       p->fwd_fused_last = fl;
       if (fl) ++gi;   // the last layer was evaluated by the fin kernel
     }
@@ -2085,10 +2088,11 @@ static int launch_tf_dw(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int kind
 }
 
 // the wide dense layer of the Inception net on the fp32 plan: K-split, weight-stationary (kernels_f32.h)
-static bool densef_ok(const BnnPlan* p, const Ctx* c, const GroupArgs& A) {
-  if (!tf_dense_ok(p, c) || p->o_dks == 0 || !A.g.is_dense || A.g.n_branch != 1 || A.g.in_bcast) return false;
+static bool densef_ok(const BnnPlan* p, const Ctx* c, const GroupArgs& A, bool bwd) {
+  if (!tf_dense_ok(p, c, bwd) || p->o_dks == 0 || !A.g.is_dense || A.g.n_branch != 1 || A.g.in_bcast) return false;
   const BranchDesc& br = A.g.br[0];
   const LayerDesc& ly = p->layers[br.layer];
+  if (c->em == EM_LRT && p->o_dksv == 0) return false;   // (a plan created for another estimator, LRT by override)
   return br.cout == 64 && br.n_off == 0 && br.in_off == 0 && br.out_off == 0 && br.cin_p == ly.cin && ly.cin % FDF_CH == 0 &&
          ly.KP == ly.cin && ly.KPt == 64 && A.t[A.g.in_t].ctot == ly.cin && A.t[br.out_t].ctot == 64 && br.relu &&
          (long)A.cg.S * A.cg.B <= p->dks_rows && ly.sign_out_words == 2 && (ly.w_off & 3) == 0 && (ly.wt_off & 3) == 0;
@@ -2102,7 +2106,8 @@ static void densef_geometry(const GroupArgs& A, int nchunk, int max_rs, int* nrs
   *rows_per_wg = ((steps + r - 1) / r) * FDF_ROWS;
 }
 
-static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last, const BnnDropout* drop) {
+static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last, const BnnDropout* drop, bool train) {
+  if (em == EM_LRT && !fuse_last) return fail(BNN_E_INVALID, "fp32 LRT dense forward needs the fused hidden / last layer launch");
   if (drop && !fuse_last) return fail(BNN_E_INVALID, "MC-dropout needs the fused hidden / last layer launch");
   const BranchDesc& br = A.g.br[0];
   const LayerDesc& ly = p->layers[br.layer];
@@ -2119,6 +2124,7 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   F.siw = ly.sign_in_words;
   F.sow = ly.sign_out_words;
   F.slab = ws_f(p, p->o_dks);
+  F.slabv = ws_f(p, p->o_dksv);
   F.slab_stride = (long)A.cg.S * A.cg.B * 64;
   F.S = A.cg.S;
   F.B = A.cg.B;
@@ -2132,6 +2138,9 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   if (em == EM_PLAIN) {
     BNN_TRY(set_lds(densef_fwd_kernel<EM_PLAIN>, FDF_LDS));
     densef_fwd_kernel<EM_PLAIN><<<dim3(grid), dim3(TF_THREADS), FDF_LDS, st>>>(F);
+  } else if (em == EM_LRT) {
+    BNN_TRY(set_lds(densef_fwd_kernel<EM_LRT>, FDF_LDS));
+    densef_fwd_kernel<EM_LRT><<<dim3(grid), dim3(TF_THREADS), FDF_LDS, st>>>(F);
   } else {
     BNN_TRY(set_lds(densef_fwd_kernel<EM_FLIPOUT>, FDF_LDS));
     densef_fwd_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TF_THREADS), FDF_LDS, st>>>(F);
@@ -2165,6 +2174,18 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
     R.g2_stride = A.gw_stride;
     R.g2_bstride = A.gb_stride;
     R.S = A.cg.S;
+    if (em == EM_LRT) {
+      R.slabv = F.slabv;
+      R.biasv = A.ws.bias_b + ly.bias_off + br.n_off;
+      R.b2v = A.ws.bias_b + l2.bias_off;
+      R.nz = A.nz;
+      R.cg = A.cg;
+      R.layer1 = br.layer;
+      R.layer2 = p->groups[gi + 1].br[0].layer;
+      R.qh = train ? (float*)A.t[br.q_t].p : nullptr;
+      R.qz = train ? (float*)A.t[p->groups[gi + 1].br[0].q_t].p : nullptr;
+      R.g2_bb = A.gb_b + l2.bias_off;
+    }
     if (drop) {
       R.drop_rate = (float)drop->p;
       R.drop_scale = (float)(1.0 / (1.0 - drop->p));
@@ -2175,6 +2196,7 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
     // one thread per (row, 4 channels); at least S * 2 * KP threads for the zeroing (surplus threads redo the last row)
     const unsigned fgrid = (unsigned)((std::max((long)R.rows * 16, (long)R.S * 2 * l2.KP) + 255) / 256);
     if (em == EM_PLAIN) densef_fin_kernel<EM_PLAIN><<<dim3(fgrid), dim3(256), 0, st>>>(R);
+    else if (em == EM_LRT) densef_fin_kernel<EM_LRT><<<dim3(fgrid), dim3(256), 0, st>>>(R);
     else densef_fin_kernel<EM_FLIPOUT><<<dim3(fgrid), dim3(256), 0, st>>>(R);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -2215,6 +2237,8 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   F.sow = ly.sign_out_words;
   F.dx = (float*)A.t[br.dx_t].p;
   F.m_x = (const unsigned char*)p->bufs.workspace + p->o_mact2;   // written by tf_fwd_kernel: dX(ACT2) is stored masked
+  F.qh = (const float*)A.t[br.q_t].p;
+  F.gb_b = A.gb_b + ly.bias_off;
   F.x_scale = drop ? (float)(1.0 / (1.0 - drop->p / 4)) : 1.f;
   F.h_scale = drop ? (float)(1.0 / (1.0 - drop->p)) : 1.f;
   F.gw_a = A.gw_a + ly.w_off;
@@ -2237,10 +2261,14 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
     F.gw2_a = ws_f(p, p->o_dw2_a) + ly.w_off;
     F.gw2_b = ws_f(p, p->o_dw2_b) + ly.w_off;
     F.gb2_a = ws_f(p, p->o_dw2_ba) + ly.bias_off;
+    F.gb2_b = ws_f(p, p->o_dw2_bb) + ly.bias_off;
     if (!g_dry) {
       if (em == EM_PLAIN) {
         BNN_TRY(set_lds(densef_dw_kernel<EM_PLAIN>, DWF_LDS));
         densef_dw_kernel<EM_PLAIN><<<dim3(grid), dim3(TF_THREADS), DWF_LDS, st>>>(F);
+      } else if (em == EM_LRT) {
+        BNN_TRY(set_lds(densef_dw_kernel<EM_LRT>, DWF_LDS));
+        densef_dw_kernel<EM_LRT><<<dim3(grid), dim3(TF_THREADS), DWF_LDS, st>>>(F);
       } else {
         BNN_TRY(set_lds(densef_dw_kernel<EM_FLIPOUT>, DWF_LDS));
         densef_dw_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TF_THREADS), DWF_LDS, st>>>(F);
@@ -2249,8 +2277,9 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
         const long n = (long)ly.cout * ly.KP;
         const dim3 ag((unsigned)((n / 4 + 255) / 256), (unsigned)F.S);
         dense_add2_kernel<<<ag, dim3(256), 0, st>>>(F.gw_a, F.gw2_a, n, F.gw_stride, F.S);
-        if (em == EM_FLIPOUT) dense_add2_kernel<<<ag, dim3(256), 0, st>>>(F.gw_b, F.gw2_b, n, F.gw_stride, F.S);
+        if (em != EM_PLAIN) dense_add2_kernel<<<ag, dim3(256), 0, st>>>(F.gw_b, F.gw2_b, n, F.gw_stride, F.S);
         dense_add2_kernel<<<dim3(1, (unsigned)F.S), dim3(256), 0, st>>>(F.gb_a, F.gb2_a, 64, F.gb_stride, F.S);
+        if (em == EM_LRT) dense_add2_kernel<<<dim3(1, (unsigned)F.S), dim3(256), 0, st>>>(F.gb_b, F.gb2_b, 64, F.gb_stride, F.S);
       }
     }
   }
@@ -2263,6 +2292,9 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
       if (em == EM_PLAIN) {
         BNN_TRY(set_lds(densef_dx_kernel<EM_PLAIN>, FDX_LDS));
         densef_dx_kernel<EM_PLAIN><<<dim3(grid), dim3(TF_THREADS), FDX_LDS, st>>>(F);
+      } else if (em == EM_LRT) {
+        BNN_TRY(set_lds(densef_dx_kernel<EM_LRT>, FDX_LDS));
+        densef_dx_kernel<EM_LRT><<<dim3(grid), dim3(TF_THREADS), FDX_LDS, st>>>(F);
       } else {
         BNN_TRY(set_lds(densef_dx_kernel<EM_FLIPOUT>, FDX_LDS));
         densef_dx_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TF_THREADS), FDX_LDS, st>>>(F);
@@ -2310,10 +2342,13 @@ static int do_head(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, float* preds,
     L.gb_a = A.gb_a + ly.bias_off;
     L.gw_stride = A.gw_stride;
     L.gb_stride = A.gb_stride;
+    L.qz = (const float*)A.t[br.q_t].p;
+    L.gb_b = A.gb_b + ly.bias_off;
     if (A.t[A.g.in_t].ctot != 64 || A.t[br.dx_t].ctot != 64) return fail(BNN_E_INVALID, "fp32 head: hidden width");
     if (g_dry) return 0;
     const dim3 hgrid((unsigned)((c->B + HL_ROWS - 1) / HL_ROWS), (unsigned)c->S);
     if (c->em == EM_PLAIN) headf_last_kernel<EM_PLAIN><<<hgrid, dim3(256), 0, c->st>>>(L);
+    else if (c->em == EM_LRT) headf_last_kernel<EM_LRT><<<hgrid, dim3(256), 0, c->st>>>(L);
     else headf_last_kernel<EM_FLIPOUT><<<hgrid, dim3(256), 0, c->st>>>(L);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -2381,9 +2416,16 @@ static int zero_grad_images(BnnPlan* p, const Ctx* c) {
 // conv layers, one workgroup per (particle, chunk) for the wide dense layer), the fill is not needed at all: the fin
 // kernel of the forward zeroed the last layer's few elements.
 static int prepare_fused_tail(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
-  c->last_fused = (trunk_ok(p, c) || (tf_bwd_ok(p, c) && tf_dense_ok(p, c))) && p->fwd_fused_last && last_fused_ok(p, c->em, p->n_groups - 2);
+  const bool tfd = tf_dense_ok(p, c);   // fp32 plan: the dense layer's fused backward reads dH from the fused head launch
+  c->last_fused = (trunk_ok(p, c) || tfd) && p->fwd_fused_last && last_fused_ok(p, c->em, p->n_groups - 2, tfd);
   if (!c->last_fused) return 0;
-  if (tf_bwd_ok(p, c) && tf_dense_ok(p, c)) {
+  if (tfd && !tf_bwd_ok(p, c)) {
+    // (the conv groups still run the generic kernels for this estimator: their dW adds with atomics)
+    BNN_TRY(zero_grad_images(p, c));
+    c->grads_zeroed = true;
+    return 0;
+  }
+  if (tfd) {
     // fp32 plan: every gradient element of the conv layers (slab reduction) and of the wide dense layer (densef_dw_kernel,
     // dense_add2_kernel) is STORED; the last layer's few elements, which the head launch adds to, were zeroed by the fin
     // kernel of the forward: no fill
@@ -2435,7 +2477,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     }
     if (A.g.is_dense && c->direct_assumed && gi == p->n_groups - 2)
       return fail(BNN_E_INVALID, "internal: the gradient images were left unfilled for the K-split dense backward, which this call does not take");
-    if (p->d.prec == BNN_PREC_F32 && densef_ok(p, c, A) && A.g.br[0].dx_t >= 0) {
+    if (p->d.prec == BNN_PREC_F32 && densef_ok(p, c, A, true) && A.g.br[0].dx_t >= 0) {
       BNN_TRY(launch_densef_bwd(p, A, c->em, c->st, &p->prof, gi, drop_on(c) ? c->drop : nullptr));
       act2_premasked = true;   // its dX is stored masked with [input > 0]
       continue;
