@@ -594,6 +594,9 @@ struct TfDxArgs {
   const uint32_t* sign_out;
   long examples;
   float drop_scale;              // MC-dropout: 1 / (1 - p/4) on dz(ACT1) (its ReLU mask carries the keep mask); else 1
+  // LRT (tf_dx_lrt_kernel): q = eps / (2 sd) of the three outputs, and the layers' input values (dX += 2 x o (sigma^2^T dVar))
+  const float* q2; const float* qm;
+  const float* act1; const float* mid;
   int S, B, L, nsplit;
 };
 
@@ -956,6 +959,304 @@ __global__ __launch_bounds__(TF_THREADS) void tf_dx_kernel(const TfDxArgs A) {
     case 5: td_role<EM, PRE, 5>(A, smem, s, split, nwin, lane); break;
     case 6: td_role<EM, PRE, 6>(A, smem, s, split, nwin, lane); break;
     default: td_role<EM, PRE, 7>(A, smem, s, split, nwin, lane); break;
+  }
+}
+
+// ==========================================================================================
+// tf_dx_lrt_kernel : the same two-stage pipeline under local reparameterisation.  Every layer has TWO gradient operands,
+// dLoc = dz and dVar = dz q (q = eps / (2 sd), kept by the forward), and
+//     dX = mu^T dLoc + 2 x o (sigma^2^T dVar)            (x = the layer's input; group_dx_kernel's EM_LRT branch)
+// so each stage keeps a mean and a variance accumulator, reads dLoc / dVar image pairs, and multiplies by the layer's
+// input in its epilogue (MID for stage A; ACT1 for stage B, its max-pooled copy - rebuilt from ACT1 with the forward's
+// DPP row rotations - for the pooled branch).  dVar(ACT2) = dY q2 is built by the loaders, dVar(MID) = dz(MID) q(MID) by
+// stage A's epilogue into a second LDS image.  The dz(MID) image pair has no halo rows (stage B's layers are 1x1).
+// ==========================================================================================
+enum {
+  TL_P2 = IMG_ROWS * TD_RS2,             // 12,672
+  TL_PM = TILE_ROWS * TF_RSB,            // 17,408: no halo rows
+  TL_O_DZ2 = 0,                          // [3 slots][dLoc, dVar]
+  TL_O_DZM = 3 * 2 * TL_P2,              // [2 bufs][dLoc, dVar]
+  TL_O_MSK = TL_O_DZM + 2 * 2 * TL_PM,   // [3 slots][m_mid | m_act1 | amax][1024]
+  TL_LDS = TL_O_MSK + 3 * 3 * 1024
+};
+static_assert(TL_LDS <= 160 * 1024, "LDS budget of tf_dx_lrt_kernel");
+
+template <int LY, int J>
+struct TlJobA {
+  static constexpr int TAPS = tl_taps(LY), PAD = (TAPS - 1) / 2, CH0 = LY == 6 ? 16 : 32, MCH = (LY == 6 ? 0 : 64) + J * 16;
+  f32x4 wa[TAPS], wb[TAPS];
+  __device__ __forceinline__ void init(const TfDxArgs& A, int s, int lane) {
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const LayerDesc ly = A.layers[LY];
+    const long ro = ly.wt_off + (long)(J * 16 + i16) * ly.KPt + 4 * g4;
+    const float* pa = (const float*)A.ws.at + A.ws.slott_stride_a * s + ro;
+    const float* pb = (const float*)A.ws.bt + A.ws.slott_stride_b * s + ro;
+#pragma unroll
+    for (int tf = 0; tf < TAPS; ++tf) {
+      wa[tf] = *(const f32x4*)(pa + tf * 16);
+      wb[tf] = *(const f32x4*)(pb + tf * 16);
+    }
+  }
+  __device__ __forceinline__ void run(const TfDxArgs& A, char* smem, int k, unsigned R0, int lane) const {
+    __builtin_amdgcn_sched_barrier(0);
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int L = A.L;
+    const char* sl = smem + TL_O_DZ2 + (k % 3) * 2 * TL_P2;
+    char* dzm = smem + TL_O_DZM + (k & 1) * 2 * TL_PM;
+    const int och = MCH + 4 * g4;
+    const unsigned char* msl = (const unsigned char*)(smem + TL_O_MSK + (k % 3) * 3072);
+    uint32_t mb[2];
+    f32x4 xin[2], qo[2];   // the layer's input (MID) and q(MID) of this lane's outputs: fetched ahead of the MFMAs
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      mb[mt] = msl[(mt * 16 + i16) * 32 + (och >> 2)];
+      const long o = (long)(R0 + (unsigned)min(mt * 16 + i16, L - 1)) * 128 + och;
+      xin[mt] = *(const f32x4*)(A.mid + o);
+      qo[mt] = *(const f32x4*)(A.qm + o);
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 accv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const char* lb = sl + i16 * TD_RS2 + (CH0 + 4 * g4) * 4;
+#pragma unroll
+    for (int tf = 0; tf < TAPS; ++tf) {
+      f32x4 x[2], xv[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        x[mt] = *(const f32x4*)(lb + (mt * 16 + tf - PAD + HALO) * TD_RS2);
+        xv[mt] = *(const f32x4*)(lb + TL_P2 + (mt * 16 + tf - PAD + HALO) * TD_RS2);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          acc[mt] = mfma4(wa[tf][j], x[mt][j], acc[mt]);
+          accv[mt] = mfma4(wb[tf][j], xv[mt][j], accv[mt]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = mt * 16 + i16;
+      if (row < L) {
+        f32x4 d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = acc[mt][r] + 2.f * xin[mt][r] * accv[mt][r];
+        d = mask4(d, mb[mt]);
+        *(f32x4*)(dzm + row * TF_RSB + och * 4) = d;
+        *(f32x4*)(dzm + TL_PM + row * TF_RSB + och * 4) = d * qo[mt];   // dVar of the 1x1 layer that produced these channels
+        *(f32x4*)((char*)A.g_mid + ((R0 + (unsigned)row) * 512u + (unsigned)(och * 4))) = d;
+      }
+    }
+  }
+};
+
+template <int CT>
+struct TlJobB {
+  f32x4 wa[11], wb[11];
+  __host__ __device__ static constexpr int q_layer(int q) { return q == 0 ? 4 : (q < 5 ? 5 : (q < 9 ? 7 : 9)); }
+  __host__ __device__ static constexpr int q_kb(int q) { return q == 0 ? 0 : (q < 5 ? q - 1 : (q < 9 ? q - 5 : q - 9)); }
+  __device__ __forceinline__ void init(const TfDxArgs& A, int s, int lane) {
+    const int i16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+      const LayerDesc ly = A.layers[q_layer(q)];
+      const long ro = ly.wt_off + (long)(CT * 16 + i16) * ly.KPt + q_kb(q) * 16 + 4 * g4;
+      wa[q] = *(const f32x4*)((const float*)A.ws.at + A.ws.slott_stride_a * s + ro);
+      wb[q] = *(const f32x4*)((const float*)A.ws.bt + A.ws.slott_stride_b * s + ro);
+    }
+  }
+  __device__ __forceinline__ void run(const TfDxArgs& A, char* smem, int k, unsigned R0, int lane) const {
+    __builtin_amdgcn_sched_barrier(0);
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int L = A.L;
+    const char* sl = smem + TL_O_DZ2 + (k % 3) * 2 * TL_P2;
+    const char* dzm = smem + TL_O_DZM + (k & 1) * 2 * TL_PM;
+    const int och = CT * 16 + 4 * g4;
+    const unsigned char* msl = (const unsigned char*)(smem + TL_O_MSK + (k % 3) * 3072);
+    uint32_t mb[2], code[2];
+    f32x4 a1[2];   // ACT1 values of this lane's outputs (the 1x1 layers' input)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = mt * 16 + i16;
+      mb[mt] = msl[1024 + row * 32 + (och >> 2)];
+      code[mt] = row < L ? (uint32_t)msl[2048 + row * 32 + (och >> 2)] : 0x55u;
+      a1[mt] = *(const f32x4*)(A.act1 + (long)(R0 + (unsigned)min(row, L - 1)) * 128 + och);
+      if (row >= L) a1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};   // rows past the window: the pool's identity (ACT1 >= 0)
+    }
+    f32x4 acc[2], accv[2], accp[2], accpv[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[mt] = accv[mt] = accp[mt] = accpv[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* b2 = sl + (i16 + HALO) * TD_RS2 + g4 * 16;
+    const char* bm = dzm + i16 * TF_RSB + g4 * 16;
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+      f32x4 x[2], xv[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const char* bp;
+        int second;
+        if (q == 0) { bp = b2 + mt * 16 * TD_RS2; second = TL_P2; }
+        else if (q >= 9) { bp = b2 + mt * 16 * TD_RS2 + (48 + (q - 9) * 16) * 4; second = TL_P2; }
+        else { bp = bm + mt * 16 * TF_RSB + (q - 1) * 64; second = TL_PM; }
+        x[mt] = *(const f32x4*)bp;
+        xv[mt] = *(const f32x4*)(bp + second);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          f32x4& ta = q >= 9 ? accp[mt] : acc[mt];
+          f32x4& tv = q >= 9 ? accpv[mt] : accv[mt];
+          ta = mfma4(wa[q][j], x[mt][j], ta);
+          tv = mfma4(wb[q][j], xv[mt][j], tv);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // MaxPool1d(3,1,1) of ACT1 at this lane's rows (the pooled layer's input), as the forward builds it: rows live on the 16
+    // lanes of a DPP row; first maximum of (row-1, row, row+1)
+    f32x4 pa[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float x0 = a1[0][r], x1 = a1[1][r];
+      const float up0 = rot16<0x121>(x0), up1 = rot16<0x121>(x1);
+      const float dn0 = rot16<0x12F>(x0), dn1 = rot16<0x12F>(x1);
+      float b0 = x0, b1 = x1;
+      if (i16 > 0) b0 = fmaxf(b0, up0);
+      b0 = fmaxf(b0, i16 == 15 ? dn1 : dn0);          // rows >= L hold 0 <= every ACT1 value
+      b1 = fmaxf(b1, i16 == 0 ? up0 : up1);
+      if (i16 < 15) b1 = fmaxf(b1, dn1);
+      pa[0][r] = b0;
+      pa[1][r] = b1;
+    }
+    f32x4 v[2], up[2], dn[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = mt * 16 + i16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[mt][r] = acc[mt][r] + 2.f * a1[mt][r] * accv[mt][r];
+        const uint32_t cd = (code[mt] >> (2 * r)) & 3u;
+        const float g = row < L ? accp[mt][r] + 2.f * pa[mt][r] * accpv[mt][r] : 0.f;
+        v[mt][r] += cd == 1u ? g : 0.f;
+        up[mt][r] = cd == 0u ? g : 0.f;
+        dn[mt][r] = cd == 2u ? g : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a0 = rot16<0x121>(dn[0][r]), a1r = rot16<0x121>(dn[1][r]);
+      const float c0 = rot16<0x12F>(up[0][r]), c1 = rot16<0x12F>(up[1][r]);
+      v[0][r] += (i16 == 0 ? 0.f : a0) + (i16 == 15 ? c1 : c0);
+      v[1][r] += (i16 == 0 ? a0 : a1r) + (i16 == 15 ? 0.f : c1);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = mt * 16 + i16;
+      if (row < L) *(f32x4*)((char*)A.g_act1 + ((R0 + (unsigned)row) * 512u + (unsigned)(och * 4))) = mask4(v[mt], mb[mt]);
+    }
+  }
+};
+
+// dY(ACT2) (premasked by the dense dX) and q(ACT2) of the next windows -> dLoc / dVar images; mask / code bytes
+struct TlLoader {
+  int qo[3], dst[3];
+  bool on[3];
+  tf_u32x4 g[3], q[3], mk;
+  const unsigned char* msrc;
+  int mdst;
+  bool mon;
+  long Rs, Rstep;
+  __device__ __forceinline__ void setup(const TfDxArgs& A, int s, int split, int lane, int p) {
+    const int n2 = A.L * 20;
+    Rs = ((long)s * A.B + split) * A.L;
+    Rstep = (long)A.nsplit * A.L;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int c = (4 * j + p) * 64 + lane;
+      on[j] = c < n2;
+      const int qq = on[j] ? c : 0;
+      qo[j] = qq * 16;
+      dst[j] = (qq / 20 + HALO) * TD_RS2 + (qq % 20) * 16;
+    }
+    const int ll = p * 64 + lane, pl = min(ll / 60, 2), c = ll - (ll / 60) * 60;
+    mon = ll < 180 && c * 16 < A.L * 32;
+    msrc = (pl == 0 ? A.m_mid : (pl == 1 ? A.m_act1 : A.amax)) + (mon ? c * 16 : 0);
+    mdst = pl * 1024 + c * 16;
+  }
+  __device__ __forceinline__ void fetch(const TfDxArgs& A, int k) {
+    const char* gp = (const char*)A.g_act2 + (Rs + k * Rstep) * 320;
+    const char* qp = (const char*)A.q2 + (Rs + k * Rstep) * 320;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      g[j] = *(const tf_u32x4*)(gp + qo[j]);
+      q[j] = *(const tf_u32x4*)(qp + qo[j]);
+    }
+    mk = *(const tf_u32x4*)(msrc + (Rs + k * Rstep) * 32);
+  }
+  __device__ __forceinline__ void put(char* smem, int k) {
+    char* sl = smem + TL_O_DZ2 + (k % 3) * 2 * TL_P2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (on[j]) {
+        *(tf_u32x4*)(sl + dst[j]) = g[j];
+        const f32x4 dv = __builtin_bit_cast(f32x4, g[j]) * __builtin_bit_cast(f32x4, q[j]);
+        *(f32x4*)(sl + TL_P2 + dst[j]) = dv;
+      }
+    }
+    if (mon) *(tf_u32x4*)(smem + TL_O_MSK + (k % 3) * 3072 + mdst) = mk;
+  }
+};
+
+template <int W>
+__device__ __forceinline__ void tl_role(const TfDxArgs& A, char* smem, int s, int split, int nwin, int lane) {
+  TlJobB<W> jb;
+  TlJobA<(W < 4 ? 6 : 8), (W & 3)> ja;
+  jb.init(A, s, lane);
+  ja.init(A, s, lane);
+  constexpr bool LOADER = W < 4;
+  TlLoader ld;
+  if constexpr (LOADER) {
+    ld.setup(A, s, split, lane, W);
+    if (nwin > 0) ld.fetch(A, 0);
+  }
+  __syncthreads();   // zero fill
+  if constexpr (LOADER) {
+    if (nwin > 0) ld.put(smem, 0);
+    if (nwin > 1) ld.fetch(A, 1);
+  }
+  lds_barrier();
+  const unsigned Rs = (unsigned)(((long)s * A.B + split) * A.L), Rstep = (unsigned)(A.nsplit * A.L);
+  const int nsteps = nwin + 1;
+  for (int t = 0; t < nsteps; ++t) {
+    if constexpr (LOADER) {
+      if (t + 1 < nwin) ld.put(smem, t + 1);
+      if (t + 2 < nwin) ld.fetch(A, t + 2);
+    }
+    if (t < nwin) ja.run(A, smem, t, Rs + t * Rstep, lane);
+    if (t >= 1) jb.run(A, smem, t - 1, Rs + (t - 1) * Rstep, lane);
+    lds_barrier();
+  }
+}
+
+__global__ __launch_bounds__(TF_THREADS) void tf_dx_lrt_kernel(const TfDxArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int s = blockIdx.x / A.nsplit, split = blockIdx.x - s * A.nsplit;
+  const int nwin = (A.B - split + A.nsplit - 1) / A.nsplit;
+  {
+    uint32_t* z = (uint32_t*)smem;
+    for (int k = tid; k < TL_LDS / 4; k += TF_THREADS) z[k] = 0u;
+  }
+  switch (wave) {
+    case 0: tl_role<0>(A, smem, s, split, nwin, lane); break;
+    case 1: tl_role<1>(A, smem, s, split, nwin, lane); break;
+    case 2: tl_role<2>(A, smem, s, split, nwin, lane); break;
+    case 3: tl_role<3>(A, smem, s, split, nwin, lane); break;
+    case 4: tl_role<4>(A, smem, s, split, nwin, lane); break;
+    case 5: tl_role<5>(A, smem, s, split, nwin, lane); break;
+    case 6: tl_role<6>(A, smem, s, split, nwin, lane); break;
+    default: tl_role<7>(A, smem, s, split, nwin, lane); break;
   }
 }
 

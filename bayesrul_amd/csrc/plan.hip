@@ -1850,7 +1850,8 @@ static bool tf_ok(const BnnPlan* p, const Ctx* c) {
 }
 // which parts of the fused fp32 path exist for the call's estimator (LRT: built stage by stage; the generic per-group
 // kernels take over where a stage is missing - they share the tensors' layout)
-static bool tf_bwd_ok(const BnnPlan* p, const Ctx* c) { return tf_ok(p, c) && c->em != EM_LRT; }
+static bool tf_dw_ok(const BnnPlan* p, const Ctx* c) { return tf_ok(p, c) && c->em != EM_LRT; }
+static bool tf_bwd_ok(const BnnPlan* p, const Ctx* c) { return tf_dw_ok(p, c); }   // every gradient element is stored (no fill needed)
 static bool tf_dense_ok(const BnnPlan* p, const Ctx* c, bool bwd = true) { (void)bwd; return tf_ok(p, c); }
 
 static int tf_check_tables(const BnnPlan* p) {
@@ -2019,9 +2020,22 @@ static int launch_tf_dx(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, bool pre
   T.L = p->d.win_length;
   T.nsplit = tf_nsplit(c);
   T.drop_scale = drop_on(c) ? (float)(1.0 / (1.0 - c->drop->p / 4)) : 1.f;
+  T.q2 = tens_ptr(p, TI_ACT2, 2);
+  T.qm = tens_ptr(p, TI_MID, 2);
+  T.act1 = tens_ptr(p, TI_ACT1, 0);
+  T.mid = tens_ptr(p, TI_MID, 0);
   static_assert(TD_LDS <= 160 * 1024, "LDS budget");
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DX, 1, c->st);
+  if (c->em == EM_LRT) {
+    ps_.name("tf_dx_lrt_kernel");
+    if (!premasked) return fail(BNN_E_INVALID, "fp32 LRT trunk dX expects dY(ACT2) premasked by the dense dX kernel");
+    BNN_DRY_RETURN();
+    BNN_TRY(set_lds(tf_dx_lrt_kernel, TL_LDS));
+    tf_dx_lrt_kernel<<<dim3(grid), dim3(TF_THREADS), TL_LDS, c->st>>>(T);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   ps_.name("tf_dx_kernel<%d, %s>", c->em, premasked ? "true" : "false");
   BNN_DRY_RETURN();
 #define LAUNCH_TFDX(EMV, PREV)                                                             \
@@ -2447,14 +2461,18 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
   for (int gi = p->n_groups - 1 - (c->last_fused ? 1 : 0); gi >= 0; --gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, a->x, &A);
-    if (!A.g.is_dense && tf_bwd_ok(p, c)) {
+    if (!A.g.is_dense && tf_ok(p, c)) {
       // fp32 conv trunk: dz of MID / ACT1 (and the masked dz of ACT2), then the two dW launches and the slab reduction
       if (gi == 2) {
         BNN_TRY(launch_tf_dx(p, a, c, act2_premasked));
-        BNN_TRY(launch_tf_dw(p, a, c, 0));
-        BNN_TRY(launch_tf_dw(p, a, c, 1));
-        BNN_TRY(reduce_trunk_slabs(p, c));
+        if (tf_dw_ok(p, c)) {
+          BNN_TRY(launch_tf_dw(p, a, c, 0));
+          BNN_TRY(launch_tf_dw(p, a, c, 1));
+          BNN_TRY(reduce_trunk_slabs(p, c));
+        }
       }
+      // (an estimator without fused dW kernels yet: the generic kernel of this group, on the masked gradients above)
+      if (!tf_dw_ok(p, c)) BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
       continue;
     }
     if (!A.g.is_dense && trunk_ok(p, c)) {
