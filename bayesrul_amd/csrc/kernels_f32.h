@@ -1281,10 +1281,18 @@ enum {
   TFW0_O_MID = TFW0_O_DZ1 + TILE_ROWS * TFW_RB, TFW0_O_DZ2 = TFW0_O_MID + IMG_ROWS * TFW_RB, TFW0_SLOT = TFW0_O_DZ2 + TILE_ROWS * TFW_RZA,
   TFW1_O_A1 = 0, TFW1_O_DZM = TFW1_O_A1 + IMG_ROWS * TFW_RB, TFW1_O_DZ2 = TFW1_O_DZM + TILE_ROWS * TFW_RB, TFW1_SLOT = TFW1_O_DZ2 + TILE_ROWS * TFW_RZB
 };
-template <int KIND> __host__ __device__ constexpr int tw_slot() { return KIND == 0 ? TFW0_SLOT : TFW1_SLOT; }
+// LRT: + the q images (q = eps / (2 sd): dVar = dz q is formed on read); x images at a 96-byte pitch so that two slots fit
+enum {
+  TFWL_RX = 96,
+  TFWL0_O_X = 0, TFWL0_O_XP = TFWL0_O_X + IMG_ROWS * TFWL_RX, TFWL0_O_DZ1 = TFWL0_O_XP + IMG_ROWS * TFWL_RX,
+  TFWL0_O_MID = TFWL0_O_DZ1 + TILE_ROWS * TFW_RB, TFWL0_O_DZ2 = TFWL0_O_MID + IMG_ROWS * TFW_RB,
+  TFWL0_O_Q1 = TFWL0_O_DZ2 + TILE_ROWS * TFW_RZA, TFWL0_O_Q2 = TFWL0_O_Q1 + TILE_ROWS * TFW_RB, TFWL0_SLOT = TFWL0_O_Q2 + TILE_ROWS * TFW_RZA,
+  TFWL1_O_QM = TFW1_SLOT, TFWL1_O_Q2 = TFWL1_O_QM + TILE_ROWS * TFW_RB, TFWL1_SLOT = TFWL1_O_Q2 + TILE_ROWS * TFW_RZB
+};
+template <int KIND, bool LRT = false> __host__ __device__ constexpr int tw_slot() { return LRT ? (KIND == 0 ? TFWL0_SLOT : TFWL1_SLOT) : (KIND == 0 ? TFW0_SLOT : TFW1_SLOT); }
 // ring of window slots: the 1x1 kind fits three (its DMAs run two steps ahead), the other kind two
-template <int KIND> __host__ __device__ constexpr int tw_nslot() { return KIND == 0 ? 2 : 3; }
-template <int KIND> __host__ __device__ constexpr int tw_lds() { return tw_nslot<KIND>() * (tw_slot<KIND>() + 80 * 4); }
+template <int KIND, bool LRT = false> __host__ __device__ constexpr int tw_nslot() { return (KIND == 0 || LRT) ? 2 : 3; }
+template <int KIND, bool LRT = false> __host__ __device__ constexpr int tw_lds() { return tw_nslot<KIND, LRT>() * (tw_slot<KIND, LRT>() + 80 * 4); }
 
 struct TfDwArgs {
   const float* xp[2];      // [B*L][20] x, pooled x
@@ -1293,48 +1301,58 @@ struct TfDwArgs {
   const float* g_act1;     // dz (masked) of ACT1 / MID / ACT2
   const float* g_mid;
   const float* g_act2;     // [S*B*L][80]
+  const float* q1; const float* qm; const float* q2;   // LRT: q planes of ACT1 / MID / ACT2
   const LayerDesc* layers;
   const uint32_t* sign_in;
   const uint32_t* sign_out;
   long examples;
   float* gw_a; float* gw_b; float* gb_a;   // slabs: [S * nsplit][gw_stride] / [S * nsplit][gb_stride]
+  float* gb_b;                             // LRT: slab of the sigma_b^2 gradients
   long gw_stride; int gb_stride;
   int S, B, L, nsplit;
 };
 
 // image geometry of a layer's operands inside a slot
-template <int KIND> __host__ __device__ constexpr int tw_zoff(int l) { return KIND == 0 ? (l < 4 ? TFW0_O_DZ1 : TFW0_O_DZ2) : ((l == 5 || l == 7) ? TFW1_O_DZM : TFW1_O_DZ2); }
+template <int KIND, bool LRT = false> __host__ __device__ constexpr int tw_zoff(int l) {
+  return KIND == 0 ? (l < 4 ? (LRT ? TFWL0_O_DZ1 : TFW0_O_DZ1) : (LRT ? TFWL0_O_DZ2 : TFW0_O_DZ2)) : ((l == 5 || l == 7) ? TFW1_O_DZM : TFW1_O_DZ2);
+}
+// LRT: the q image that goes with a layer's dz image (same pitch, same channels)
+template <int KIND> __host__ __device__ constexpr int tw_qoff(int l) {
+  return KIND == 0 ? (l < 4 ? TFWL0_O_Q1 : TFWL0_O_Q2) : ((l == 5 || l == 7) ? TFWL1_O_QM : TFWL1_O_Q2);
+}
 template <int KIND> __host__ __device__ constexpr int tw_zpitch(int l) { return KIND == 0 ? (l < 4 ? TFW_RB : TFW_RZA) : ((l == 5 || l == 7) ? TFW_RB : TFW_RZB); }
 template <int KIND> __host__ __device__ constexpr int tw_zch(int l) { return KIND == 0 ? (l < 4 ? l * 32 : (l == 6 ? 0 : 16)) : (l == 7 ? 64 : (l == 9 ? 48 : 0)); }
-template <int KIND> __host__ __device__ constexpr int tw_xoff(int l) { return KIND == 0 ? (l < 3 ? TFW0_O_X : (l == 3 ? TFW0_O_XP : TFW0_O_MID)) : TFW1_O_A1; }
-template <int KIND> __host__ __device__ constexpr int tw_xpitch(int l) { return KIND == 0 ? (l < 4 ? TFW_RX : TFW_RB) : TFW_RB; }
+template <int KIND, bool LRT = false> __host__ __device__ constexpr int tw_xoff(int l) {
+  return KIND == 0 ? (l < 3 ? (LRT ? TFWL0_O_X : TFW0_O_X) : (l == 3 ? (LRT ? TFWL0_O_XP : TFW0_O_XP) : (LRT ? TFWL0_O_MID : TFW0_O_MID))) : TFW1_O_A1;
+}
+template <int KIND, bool LRT = false> __host__ __device__ constexpr int tw_xpitch(int l) { return KIND == 0 ? (l < 4 ? (LRT ? TFWL_RX : TFW_RX) : TFW_RB) : TFW_RB; }
 __host__ __device__ constexpr int tw_xch(int l) { return l == 8 ? 64 : 0; }
 
 // one (layer, n-tile) job over the c-tiles [CT0, CT0 + NCT) of the layer's own input channels, all taps
 template <int EM, int KIND, int LY, int NT, int CT0, int NCT, bool BIAS>
 struct TwJob {
-  static constexpr bool FO = (EM == EM_FLIPOUT);
+  static constexpr bool FO = (EM == EM_FLIPOUT), LRT = (EM == EM_LRT), TWO = FO || LRT;
   static constexpr int TAPS = tl_taps(LY), PAD = (TAPS - 1) / 2, NTILE = TAPS * NCT;
   static constexpr bool POOL3 = (KIND == 1 && LY == 9);
-  f32x4 acc_a[NTILE], acc_b[FO ? NTILE : 1];
-  float bsum;
+  f32x4 acc_a[NTILE], acc_b[TWO ? NTILE : 1];
+  float bsum, bsumv;
 
   __device__ __forceinline__ void init() {
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
       acc_a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (FO) acc_b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (TWO) acc_b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    bsum = 0.f;
+    bsum = bsumv = 0.f;
   }
 
   __device__ __forceinline__ void load_a(const char* sl, int tt, int lane, float (&ax)[8]) const {
     const int i16 = lane & 15, g4 = lane >> 4;
     const int tap = tt / NCT, c = tt - tap * NCT;
-    const char* xi = sl + tw_xoff<KIND>(LY) + (tw_xch(LY) + (CT0 + c) * 16 + i16) * 4 + (g4 + tap - PAD + HALO) * tw_xpitch<KIND>(LY);
+    const char* xi = sl + tw_xoff<KIND, LRT>(LY) + (tw_xch(LY) + (CT0 + c) * 16 + i16) * 4 + (g4 + tap - PAD + HALO) * tw_xpitch<KIND, LRT>(LY);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const char* q = xi + 4 * ks * tw_xpitch<KIND>(LY);
+      const char* q = xi + 4 * ks * tw_xpitch<KIND, LRT>(LY);
       if constexpr (POOL3) ax[ks] = fmaxf(fmaxf(*(const float*)(q - TFW_RB), *(const float*)q), *(const float*)(q + TFW_RB));
       else ax[ks] = *(const float*)q;
     }
@@ -1366,10 +1384,41 @@ struct TwJob {
     __builtin_amdgcn_sched_barrier(0);
     const int i16 = lane & 15, g4 = lane >> 4;
     constexpr int n0 = tw_zch<KIND>(LY) + NT * 16;
-    const char* zi = sl + tw_zoff<KIND>(LY) + g4 * tw_zpitch<KIND>(LY) + (n0 + i16) * 4;
+    const char* zi = sl + tw_zoff<KIND, LRT>(LY) + g4 * tw_zpitch<KIND>(LY) + (n0 + i16) * 4;
     float bz[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) bz[ks] = *(const float*)(zi + 4 * ks * tw_zpitch<KIND>(LY));
+    if constexpr (LRT) {
+      // d mu = dLoc^T x, d sigma^2 = dVar^T x^2 (dLoc = dz, dVar = dz q): two contractions with their own operands on both
+      // sides, chained straight into the accumulators (no sign fold)
+      float bzv[8];
+      const char* qi = sl + tw_qoff<KIND>(LY) + g4 * tw_zpitch<KIND>(LY) + (n0 + i16) * 4;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) bzv[ks] = bz[ks] * *(const float*)(qi + 4 * ks * tw_zpitch<KIND>(LY));
+      if constexpr (BIAS) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          bsum += bz[ks];
+          bsumv += bzv[ks];
+        }
+      }
+      float axc[8], axn[8];
+      load_a(sl, 0, lane, axc);
+#pragma unroll
+      for (int tt = 0; tt < NTILE; ++tt) {
+        if (tt + 1 < NTILE) load_a(sl, tt + 1, lane, axn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          acc_a[tt] = mfma4(axc[ks], bz[ks], acc_a[tt]);
+          acc_b[tt] = mfma4(axc[ks] * axc[ks], bzv[ks], acc_b[tt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) axc[ks] = axn[ks];
+      }
+      return;
+    }
     // the window's sign words of this layer, once per job (registers: no LDS read inside the MFMA stream)
     uint32_t siw[4] = {0u, 0u, 0u, 0u}, sobx = 0;
     if constexpr (FO) {
@@ -1420,7 +1469,7 @@ struct TwJob {
         // transposed tile: this lane holds the image channels ch .. ch+3 of cout n (channel pads are zero columns)
         const long o = (long)n * ly.KP + (long)tap * ly.cin_img + (CT0 + c) * 16 + 4 * g4;
         *(f32x4*)(gwa + o) = acc_a[tt];
-        if constexpr (FO) *(f32x4*)(gwb + o) = acc_b[tt];
+        if constexpr (TWO) *(f32x4*)(gwb + o) = acc_b[tt];
       }
     }
     if constexpr (BIAS) {
@@ -1428,6 +1477,12 @@ struct TwJob {
       t += __shfl_xor(t, 16, 64);
       t += __shfl_xor(t, 32, 64);
       if (g4 == 0 && n < ly.cout) A.gb_a[(long)A.gb_stride * slab + ly.bias_off + n] = t;
+      if constexpr (LRT) {
+        float tv = bsumv;
+        tv += __shfl_xor(tv, 16, 64);
+        tv += __shfl_xor(tv, 32, 64);
+        if (g4 == 0 && n < ly.cout) A.gb_b[(long)A.gb_stride * slab + ly.bias_off + n] = tv;
+      }
     }
   }
 };
@@ -1451,20 +1506,20 @@ struct TwStream {
   int spr;            // LDS slots per row (pitch / 16)
   int dstoff;         // byte offset of row 0 inside a slot of the ring
 };
-enum { TFW_NDMA = 7 };
-template <bool FO>
+enum { TFW_NDMA = 7, TFWL_NDMA = 9 };   // DMA instructions per wave and window (LRT stages the q images too)
+template <bool FO, int ND>
 struct TwDma {
-  const char* src[TFW_NDMA];
-  int wstep[TFW_NDMA];
-  uint32_t dst[TFW_NDMA];
-  bool on[TFW_NDMA];
+  const char* src[ND];
+  int wstep[ND];
+  uint32_t dst[ND];
+  bool on[ND];
   const uint32_t* sg0 = nullptr;
   const uint32_t* sg1 = nullptr;
   long sst0 = 0, sst1 = 0;
   __device__ __forceinline__ void setup(const TfDwArgs& A, const TwStream* st, int nst, int s, int split, int wave, int lane) {
     const int L = A.L;
 #pragma unroll
-    for (int j = 0; j < TFW_NDMA; ++j) {
+    for (int j = 0; j < ND; ++j) {
       int g = j * TF_WAVES + wave;   // instruction index inside the window
       on[j] = false;
       src[j] = st[0].base;
@@ -1504,14 +1559,14 @@ struct TwDma {
   __device__ __forceinline__ int count() const {
     int n = 0;
 #pragma unroll
-    for (int j = 0; j < TFW_NDMA; ++j) n += __builtin_amdgcn_ballot_w64(on[j]) != 0 ? 1 : 0;
+    for (int j = 0; j < ND; ++j) n += __builtin_amdgcn_ballot_w64(on[j]) != 0 ? 1 : 0;
     if constexpr (FO) n += (__builtin_amdgcn_ballot_w64(sg0 != nullptr) != 0 ? 1 : 0) + (__builtin_amdgcn_ballot_w64(sg1 != nullptr) != 0 ? 1 : 0);
     return n;
   }
   // window k -> ring slot at LDS byte address `slot`, its sign words at `sgw`
   __device__ __forceinline__ void issue(int k, uint32_t slot, uint32_t sgw) {
 #pragma unroll
-    for (int j = 0; j < TFW_NDMA; ++j)
+    for (int j = 0; j < ND; ++j)
       if (on[j]) dma16(src[j] + (long)k * wstep[j], __builtin_amdgcn_readfirstlane(slot + dst[j]));
     if constexpr (FO) {
       if (sg0) dma4(sg0 + (long)k * sst0, __builtin_amdgcn_readfirstlane(sgw));
@@ -1522,8 +1577,8 @@ struct TwDma {
 
 template <int EM, int KIND, class J0, class J1, class J2>
 __device__ __forceinline__ void tw_role(const TfDwArgs& A, char* smem, const TwStream* st, int nst, int s, int split, int nwin, int tid) {
-  constexpr bool FO = (EM == EM_FLIPOUT);
-  constexpr int SLOT = tw_slot<KIND>();
+  constexpr bool FO = (EM == EM_FLIPOUT), LRT = (EM == EM_LRT);
+  constexpr int SLOT = tw_slot<KIND, LRT>();
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   J0 j0;
@@ -1532,9 +1587,9 @@ __device__ __forceinline__ void tw_role(const TfDwArgs& A, char* smem, const TwS
   j0.init();
   j1.init();
   j2.init();
-  TwDma<FO> ld;
+  TwDma<FO, (LRT ? TFWL_NDMA : TFW_NDMA)> ld;
   ld.setup(A, st, nst, s, split, wave, lane);
-  constexpr int NS = tw_nslot<KIND>(), AHEAD = NS - 1;
+  constexpr int NS = tw_nslot<KIND, LRT>(), AHEAD = NS - 1;
   const int nper = ld.count();
   const uint32_t lds0 = lds_addr(smem), sgb0 = lds0 + NS * SLOT;
   const uint32_t* sgb = (const uint32_t*)(smem + NS * SLOT);
@@ -1573,12 +1628,29 @@ __global__ __launch_bounds__(TF_THREADS) void tf_dw_kernel(const TfDwArgs A) {
   const int L = A.L;
   {
     uint32_t* z = (uint32_t*)smem;
-    for (int k = tid; k < tw_lds<KIND>() / 4; k += TF_THREADS) z[k] = 0u;
+    for (int k = tid; k < tw_lds<KIND, EM == EM_LRT>() / 4; k += TF_THREADS) z[k] = 0u;
   }
+  constexpr bool LRT = (EM == EM_LRT);
   const long pr = ((long)s * A.B + split) * L;   // first row of this workgroup's window 0 in the [S*B*L] row space
-  TwStream st[5];
+  TwStream st[7];
   int nst;
-  if constexpr (KIND == 0) {
+  if constexpr (KIND == 0 && LRT) {
+    st[0] = TwStream{(const char*)A.xp[0] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFWL_RX / 16, TFWL0_O_X + HALO * TFWL_RX};
+    st[1] = TwStream{(const char*)A.xp[1] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFWL_RX / 16, TFWL0_O_XP + HALO * TFWL_RX};
+    st[2] = TwStream{(const char*)A.g_act1 + pr * 512, 512, 32, TFW_RB / 16, TFWL0_O_DZ1};
+    st[3] = TwStream{(const char*)A.mid + pr * 512, 512, 32, TFW_RB / 16, TFWL0_O_MID + HALO * TFW_RB};
+    st[4] = TwStream{(const char*)A.g_act2 + pr * 320 + 64, 320, 8, TFW_RZA / 16, TFWL0_O_DZ2};
+    st[5] = TwStream{(const char*)A.q1 + pr * 512, 512, 32, TFW_RB / 16, TFWL0_O_Q1};
+    st[6] = TwStream{(const char*)A.q2 + pr * 320 + 64, 320, 8, TFW_RZA / 16, TFWL0_O_Q2};
+    nst = 7;
+  } else if constexpr (KIND == 1 && LRT) {
+    st[0] = TwStream{(const char*)A.act1 + pr * 512, 512, 32, TFW_RB / 16, TFW1_O_A1 + HALO * TFW_RB};
+    st[1] = TwStream{(const char*)A.g_mid + pr * 512, 512, 32, TFW_RB / 16, TFW1_O_DZM};
+    st[2] = TwStream{(const char*)A.g_act2 + pr * 320, 320, 20, TFW_RZB / 16, TFW1_O_DZ2};
+    st[3] = TwStream{(const char*)A.qm + pr * 512, 512, 32, TFW_RB / 16, TFWL1_O_QM};
+    st[4] = TwStream{(const char*)A.q2 + pr * 320, 320, 20, TFW_RZB / 16, TFWL1_O_Q2};
+    nst = 5;
+  } else if constexpr (KIND == 0) {
     st[0] = TwStream{(const char*)A.xp[0] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFW_RX / 16, TFW0_O_X + HALO * TFW_RX};
     st[1] = TwStream{(const char*)A.xp[1] + (long)split * L * (TF_XC * 4), TF_XC * 4, 5, TFW_RX / 16, TFW0_O_XP + HALO * TFW_RX};
     st[2] = TwStream{(const char*)A.g_act1 + pr * 512, 512, 32, TFW_RB / 16, TFW0_O_DZ1};

@@ -813,7 +813,7 @@ struct SlabReduceArgs {
 
 // the (up to) three reductions of a step - slot A, slot B, bias sums - in one launch: blockIdx.z picks the job
 struct SlabReduceJobs {
-  SlabReduceArgs job[3];
+  SlabReduceArgs job[4];
 };
 
 __global__ void slab_reduce_kernel(const SlabReduceJobs J) {

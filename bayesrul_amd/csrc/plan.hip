@@ -135,6 +135,7 @@ struct BnnPlan {
   // workspace layout (byte offsets)
   size_t ws_bytes = 0;
   size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
+  size_t o_slab_bb = 0;                            // fp32 LRT: partial sums of the sigma_b^2 gradients
   size_t o_dw2_a = 0, o_dw2_b = 0, o_dw2_ba = 0, o_dw2_bb = 0;   // fp32 plan: second partial images of the wide dense layer's dW
   size_t o_dksv = 0;                               // fp32 LRT plan: partial variances of the K-split dense forward
   size_t o_mact2 = 0;                              // fp32 plan: nibble masks [ACT2 > 0] ([rows][20 B])
@@ -426,6 +427,7 @@ static void layout_workspace(BnnPlan* p) {
       p->o_slab_ba[g] = g < ngrp ? take((size_t)p->slab_slots[g] * p->slab_bstride * 4) : p->o_slab_ba[gs];
       if (g >= ngrp) p->slab_slots[g] = p->slab_slots[gs];
     }
+    if (p->d.prec == BNN_PREC_F32) p->o_slab_bb = take((size_t)p->slab_slots[0] * p->slab_bstride * 4);
   }
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_LINEAR && p->layers[0].KP == ML_K0 && p->layers[0].cout == ML_N0 &&
       p->layers[1].cout == ML_N1 && p->layers[2].cout == ML_N2 && p->layers[3].cout == ML_N3 && p->layers[4].cout == ML_N4) {
@@ -1850,7 +1852,7 @@ static bool tf_ok(const BnnPlan* p, const Ctx* c) {
 }
 // which parts of the fused fp32 path exist for the call's estimator (LRT: built stage by stage; the generic per-group
 // kernels take over where a stage is missing - they share the tensors' layout)
-static bool tf_dw_ok(const BnnPlan* p, const Ctx* c) { return tf_ok(p, c) && c->em != EM_LRT; }
+static bool tf_dw_ok(const BnnPlan* p, const Ctx* c) { return tf_ok(p, c); }
 static bool tf_bwd_ok(const BnnPlan* p, const Ctx* c) { return tf_dw_ok(p, c); }   // every gradient element is stored (no fill needed)
 static bool tf_dense_ok(const BnnPlan* p, const Ctx* c, bool bwd = true) { (void)bwd; return tf_ok(p, c); }
 
@@ -2071,16 +2073,20 @@ static int launch_tf_dw(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int kind
   T.sign_out = c->nz.sign_out;
   T.examples = (long)c->S * c->B;
   T.gw_a = ws_f(p, p->o_slab_a[0]); T.gw_b = ws_f(p, p->o_slab_b[0]); T.gb_a = ws_f(p, p->o_slab_ba[0]);
+  T.gb_b = ws_f(p, p->o_slab_bb);
+  T.q1 = tens_ptr(p, TI_ACT1, 2); T.qm = tens_ptr(p, TI_MID, 2); T.q2 = tens_ptr(p, TI_ACT2, 2);
   T.gw_stride = p->slab_stride; T.gb_stride = p->slab_bstride;
   T.S = c->S; T.B = c->B; T.L = p->d.win_length;
   T.nsplit = tf_nsplit(c);
   BNN_TRY(check_slab_slots(p, c, 0, T.nsplit));
-  static_assert(tw_lds<0>() <= 160 * 1024 && tw_lds<1>() <= 160 * 1024, "LDS budgets");
+  static_assert(tw_lds<0>() <= 160 * 1024 && tw_lds<1>() <= 160 * 1024 && tw_lds<0, true>() <= 160 * 1024 && tw_lds<1, true>() <= 160 * 1024, "LDS budgets");
   {
     // LDS-DMA instructions per window (64 slots of 16 B each, pad slots included) against the 8 x TFW_NDMA the waves issue
     auto ni = [&](int spr) { return (T.L * spr + 63) / 64; };
     const int n0 = 3 * ni(TFW_RX / 16) + 2 * ni(TFW_RB / 16), n1 = 2 * ni(TFW_RB / 16) + ni(TFW_RZB / 16);
     if (std::max(n0, n1) > TFW_NDMA * TF_WAVES) return fail(BNN_E_INVALID, "fp32 trunk dW: window too long for the staging plan");
+    const int l0 = 2 * ni(TFWL_RX / 16) + 3 * ni(TFW_RB / 16) + 2 * ni(TFW_RZA / 16), l1 = 3 * ni(TFW_RB / 16) + 2 * ni(TFW_RZB / 16);
+    if (c->em == EM_LRT && std::max(l0, l1) > TFWL_NDMA * TF_WAVES) return fail(BNN_E_INVALID, "fp32 LRT trunk dW: window too long for the staging plan");
   }
   const unsigned grid = (unsigned)(c->S * T.nsplit);
   ProfScope ps_(&p->prof, PK_DW, kind == 0 ? 0 : 1, c->st);
@@ -2091,7 +2097,15 @@ static int launch_tf_dw(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int kind
     BNN_TRY(set_lds((tf_dw_kernel<EMV, KV>), tw_lds<KV>()));                                        \
     tf_dw_kernel<EMV, KV><<<dim3(grid), dim3(TF_THREADS), tw_lds<KV>(), c->st>>>(T);                \
   } while (0)
-  if (c->em == EM_FLIPOUT) {
+  if (c->em == EM_LRT) {
+#define LAUNCH_TFDWL(KV)                                                                               \
+  do {                                                                                               \
+    BNN_TRY(set_lds((tf_dw_kernel<EM_LRT, KV>), (tw_lds<KV, true>())));                              \
+    tf_dw_kernel<EM_LRT, KV><<<dim3(grid), dim3(TF_THREADS), (tw_lds<KV, true>()), c->st>>>(T);      \
+  } while (0)
+    if (kind == 0) LAUNCH_TFDWL(0); else LAUNCH_TFDWL(1);
+#undef LAUNCH_TFDWL
+  } else if (c->em == EM_FLIPOUT) {
     if (kind == 0) LAUNCH_TFDW(EM_FLIPOUT, 0); else LAUNCH_TFDW(EM_FLIPOUT, 1);
   } else {
     if (kind == 0) LAUNCH_TFDW(EM_PLAIN, 0); else LAUNCH_TFDW(EM_PLAIN, 1);
@@ -2562,20 +2576,22 @@ static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c) {
   static thread_local SlabReduceJobs J;
   int nj = 0;
   long max_elems = 0;
-  for (int which = 0; which < 3; ++which) {   // 0: slot A, 1: slot B (Flipout's dW part), 2: bias sums
+  const bool f32p = p->d.prec == BNN_PREC_F32;
+  for (int which = 0; which < 4; ++which) {   // 0: slot A, 1: slot B (Flipout's dW | LRT's sigma^2 part), 2: bias sums, 3: LRT's sigma_b^2 sums
     if (which == 1 && c->em == EM_PLAIN) continue;
-    if (which == 2 && c->em == EM_LRT) continue;   // the per-group LRT kernels add their bias sums with atomics
+    if (which == 2 && c->em == EM_LRT && !f32p) continue;   // the per-group bf16 LRT kernels add their bias sums with atomics
+    if (which == 3 && !(c->em == EM_LRT && f32p)) continue;
     SlabReduceArgs& R = J.job[nj++];
     R = SlabReduceArgs{};
     for (int g = 0; g < 3; ++g) {
-      R.slab[g] = ws_f(p, which == 0 ? p->o_slab_a[g] : (which == 1 ? p->o_slab_b[g] : p->o_slab_ba[g]));
+      R.slab[g] = ws_f(p, which == 0 ? p->o_slab_a[g] : (which == 1 ? p->o_slab_b[g] : (which == 2 ? p->o_slab_ba[g] : p->o_slab_bb)));
       R.n[g] = p->d.prec == BNN_PREC_F32 ? tf_nsplit(c) : (c->em == EM_LRT ? conv_dw_nsplit(c) : trunk_dw_nsplit(c, g));
     }
-    R.stride = which == 2 ? p->slab_bstride : p->slab_stride;
-    for (int l = 0; l < 10; ++l) R.lay_end[l] = which == 2 ? p->layers[l + 1].bias_off : p->layers[l + 1].w_off;
+    R.stride = which >= 2 ? p->slab_bstride : p->slab_stride;
+    for (int l = 0; l < 10; ++l) R.lay_end[l] = which >= 2 ? p->layers[l + 1].bias_off : p->layers[l + 1].w_off;
     R.elems = R.lay_end[9];
-    R.out = ws_f(p, which == 0 ? p->o_gw_a : (which == 1 ? p->o_gw_b : p->o_gb_a));
-    R.out_stride = which == 2 ? p->bias_total : p->img_total;
+    R.out = ws_f(p, which == 0 ? p->o_gw_a : (which == 1 ? p->o_gw_b : (which == 2 ? p->o_gb_a : p->o_gb_b)));
+    R.out_stride = which >= 2 ? p->bias_total : p->img_total;
     R.S = c->S;
     max_elems = std::max(max_elems, R.elems);
   }

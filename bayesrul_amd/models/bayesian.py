@@ -117,11 +117,11 @@ class BNN(_Base):
         eval_windows = max(S * B, min(hp.mc_samples_eval * hp.max_eval_batch, 200_000))
         # precision plan: "f32" = exact-fp32 MFMA, the reference's arithmetic (conf/trainer/default.yaml:8-12 trains in fp32);
         # "bf16x3" = split-bf16 (faster, looser gradients: tests/test_gpu_bnn_surface.py::test_200_step_fit_...).  "auto": f32
-        # wherever fused fp32 kernels exist (Inception with Flipout / radial / plain sampling); LRT and the Linear net have
-        # fused kernels on the bf16x3 plan only (their f32 plan runs the generic per-group kernels, ~10x slower)
+        # wherever fused fp32 kernels exist (the Inception net, every estimator); the Linear net has fused kernels on the
+        # bf16x3 plan only (its f32 plan runs the generic per-group kernels, ~15x slower)
         prec = hp.prec
         if prec == "auto":
-            prec = "f32" if (net_kind == "inception" and hp.fit_context != "lrt") else "bf16x3"
+            prec = "f32" if net_kind == "inception" else "bf16x3"
         self.engine = SviEngine(net=net_kind, guide=hp.guide, fit_context=hp.fit_context, prec=prec, max_particles=S,
                                 max_batch=max(B, hp.max_eval_batch), win_length=self.net.win_length,
                                 n_features=self.net.n_features, device=self.device, max_windows=eval_windows)

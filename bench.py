@@ -42,9 +42,9 @@ WORKLOADS = {
     # (BASELINE.json names bf16 for this config: its default plan is the split-bf16 one)
     "lrt_linear_s1": dict(net="linear", guide="normal", fit_context="lrt", S=1, B=1000,
                           prior_scale=0.138793, q_scale=0.001351, lr=8.57e-4, prec="bf16x3"),
-    # the reference's shipped LRT experiment (ncmapss_lrt.yaml); LRT has fused kernels on the split-bf16 plan only
+    # the reference's shipped LRT experiment (ncmapss_lrt.yaml)
     "lrt_conv_s1": dict(net="inception", guide="normal", fit_context="lrt", S=1, B=1000,
-                        prior_scale=0.138793, q_scale=0.001351, lr=8.57e-4, prec="bf16x3"),
+                        prior_scale=0.138793, q_scale=0.001351, lr=8.57e-4),
     # configs[4]: Flipout-trained Conv BNN, 100-sample predictive pass (tasks/predict.py:24-64, bayesian.py:231-250):
     # plain Normal sampling, forward only, 10,000 windows per batch (conf/datamodule/ncmapss.yaml:4); a "step" is
     # one predictive pass over the batch incl. the ep/al variance aggregation
@@ -61,7 +61,8 @@ GROUP_MACS = {
 }
 N_PARAMS = {"inception": 187142, "linear": 192098}
 # branch groups one launch of a fused kernel covers (the library reports the symbol per (kind, group) tag)
-FUSED_GROUPS = {"trunk_fwd_kernel": (0, 1, 2), "trunk_dx_kernel": (1, 2), "tf_fwd_kernel": (0, 1, 2), "tf_dx_kernel": (1, 2)}
+FUSED_GROUPS = {"trunk_fwd_kernel": (0, 1, 2), "trunk_dx_kernel": (1, 2), "tf_fwd_kernel": (0, 1, 2), "tf_dx_kernel": (1, 2),
+                "tf_dx_lrt_kernel": (1, 2)}
 # the fp32 plan's dW launches: kind 0 = block 1 + the k3 / k5 level, kind 1 = the 1x1 level (keyed by the profile tag's group)
 FUSED_DW_GROUPS = {"tf_dw_kernel": {0: (0, 2), 1: (1,)}}
 PEAK_TFLOPS = {"bf16x3": 2500.0, "f32": 157.3}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
