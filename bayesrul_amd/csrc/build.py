@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libbayesrul_amd.so")
 SOURCES = ["plan.hip"]
 NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-HEADERS = ["common.h", "desc.h", "kernels_core.h", "kernels_group.h", "kernels_misc.h", "kernels_conv_bf.h", "kernels_conv_dx.h", "kernels_dense_fwd.h", "kernels_trunk.h", "kernels_trunk_bwd.h", "kernels_trunk_dw.h", "kernels_dense_ks.h", "kernels_mlp.h", "kernels_f32.h",
+HEADERS = ["common.h", "desc.h", "kernels_core.h", "kernels_group.h", "kernels_misc.h", "kernels_conv_bf.h", "kernels_dense_fwd.h", "kernels_trunk.h", "kernels_trunk_bwd.h", "kernels_trunk_dw.h", "kernels_dense_ks.h", "kernels_mlp.h", "kernels_f32.h",
            os.path.join("..", "..", "include", "bayesrul_amd.h")]
 
 

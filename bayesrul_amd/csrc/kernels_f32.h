@@ -12,8 +12,12 @@
 //
 // Reference arithmetic: nets/inception.py:10-132 (both inception blocks), [3P] tyxe.poutine.flipout (bayesian.py:68-69).
 #pragma once
-// diagnostics builds only (tests/probes/ablate_gpu.sh): TFV bit 1 = dW without the fold arithmetic, 2 = forward without epilogue, 4 = dW without its DMAs
-// (results wrong); the product library is built with TFV == 0.
+// diagnostics builds only (tests/probes/ablate_gpu.sh, results wrong): TFV bit 1 = dW without the fold arithmetic, 2 = forward
+// without epilogue, 4 = dW without its DMAs, 8 = forward without LDS operand reads in the k loop, 32 = forward without global
+// stores, 64 = forward without max-pooling; the product library is built with TFV == 0.
+#ifndef TF_STAMPS
+#define TF_STAMPS 0   // diagnostics builds (tests/probes/ablate_gpu.sh): s_memtime stamps of workgroup 0's waves
+#endif
 #ifndef TFV
 #define TFV 0
 #endif
@@ -73,7 +77,19 @@ struct TfArgs {
   CallGeom cg;
   float* q1; float* qm; float* q2;   // q = eps / (2 sd) of ACT1 / MID / ACT2 outputs (training step: the backward's d out / d var)
   int S, B, L, nsplit;
+#if TF_STAMPS
+  unsigned long long* dbg;   // [8 waves][48 steps][16 phases]
+#endif
 };
+#if TF_STAMPS
+#define TF_STAMP_AT(P, STEP, PH)                                                                                              \
+  do {                                                                                                                        \
+    if ((P) && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (STEP) < 48)                                                      \
+      (P)[(((threadIdx.x >> 6) * 48 + (STEP)) * 16) + (PH)] = __builtin_amdgcn_s_memtime();                                   \
+  } while (0)
+#else
+#define TF_STAMP_AT(P, STEP, PH) do {} while (0)
+#endif
 
 // keep mask of 4 consecutive channels of one row: injected floats, or one Philox call (4 x 32 uniform bits)
 __device__ __forceinline__ uint32_t drop_keep4(const float* inj, long o, float rate, uint32_t row, uint32_t quad, uint32_t which,
@@ -155,7 +171,7 @@ struct TfJobRun {
   }
 
   // k = index of the window inside this workgroup's list; R0 = first row of the window in the [S*B*L] row space
-  __device__ __forceinline__ void run(const TfArgs& A, char* smem, int k, unsigned R0, int lane) const {
+  __device__ __forceinline__ void run(const TfArgs& A, char* smem, int k, unsigned R0, int lane, int st_step = 0, int st_ph = 0) const {
     __builtin_amdgcn_sched_barrier(0);
     const int i16 = lane & 15, g4 = lane >> 4;
     const int par = k & 1;
@@ -209,8 +225,12 @@ struct TfJobRun {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
       const int tap = kb / CB, cb = kb - tap * CB;
-      if (kb + 1 < NKB) fetch(kb + 1, nxt);
+      if constexpr (TFV & 8) nxt = cur;   // diagnostics: no LDS operand traffic inside the k loop (results wrong)
+      else if (kb + 1 < NKB) fetch(kb + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
+#if TF_STAMPS
+      if (st_ph == 4 && kb < 7) TF_STAMP_AT(A.dbg, st_step, 9 + kb);
+#endif
       // consecutive MFMAs alternate between the two accumulators (dependent issue distance 64 cycles > 40 latency)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -252,6 +272,10 @@ struct TfJobRun {
       cur = nxt;
     }
     __builtin_amdgcn_sched_barrier(0);
+#if TF_STAMPS
+    asm volatile("" ::"v"(acc[0]), "v"(acc[1]));   // (issue of the last MFMA; its result is waited for by the epilogue)
+    TF_STAMP_AT(A.dbg, st_step, st_ph);
+#endif
     // ---------------- epilogue: ReLU (every conv of the trunk is followed by one: inception.py:48-60, 118-131) ----------------
     if constexpr (TFV & 2) {
       asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
@@ -321,15 +345,15 @@ struct TfJobRun {
         if constexpr (OUTK == 0 || OUTK == 1) {
           char* img = smem + (OUTK == 0 ? TF_A1B + par * 2 * TF_PA : TF_O_MID + par * TF_PB);
           *(f32x4*)(img + (row + HALO) * TF_RSB + (OOFF + chb) * 4) = v[mt];
-          if constexpr (TRAIN) {
+          if constexpr (TRAIN && !(TFV & 32)) {
             char* g = (char*)(OUTK == 0 ? A.act1 : A.mid);
             *(f32x4*)(g + ((R0 + (unsigned)row) * 512u + (unsigned)((OOFF + chb) * 4))) = v[mt];
             const uint32_t bits = (v[mt][0] > 0.f ? 1u : 0u) | (v[mt][1] > 0.f ? 2u : 0u) | (v[mt][2] > 0.f ? 4u : 0u) | (v[mt][3] > 0.f ? 8u : 0u);
             (OUTK == 0 ? A.m_act1 : A.m_mid)[(R0 + (unsigned)row) * 32u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)bits;
           }
         } else {
-          *(f32x4*)((char*)A.act2 + ((R0 + (unsigned)row) * 320u + (unsigned)((OOFF + chb) * 4))) = v[mt];
-          if constexpr (TRAIN) {
+          if constexpr (!(TFV & 32)) *(f32x4*)((char*)A.act2 + ((R0 + (unsigned)row) * 320u + (unsigned)((OOFF + chb) * 4))) = v[mt];
+          if constexpr (TRAIN && !(TFV & 32)) {
             const uint32_t bits = (v[mt][0] > 0.f ? 1u : 0u) | (v[mt][1] > 0.f ? 2u : 0u) | (v[mt][2] > 0.f ? 4u : 0u) | (v[mt][3] > 0.f ? 8u : 0u);
             A.m_act2[(R0 + (unsigned)row) * 20u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)bits;
           }
@@ -337,7 +361,7 @@ struct TfJobRun {
       }
     }
     // ---------------- block 1 only: MaxPool1d(3,1,1) of the output rows (inception.py:99-104 reads it) ----------------
-    if constexpr (OUTK == 0) {
+    if constexpr (OUTK == 0 && !(TFV & 64)) {
       // rows live on the 16 lanes of a DPP row: row-1 / row+1 are one lane away; the seam between the two
       // m-tiles (rows 15 | 16) takes the other accumulator.  torch keeps the FIRST maximum of (row-1, row, row+1).
       f32x4 p[2];
@@ -372,7 +396,7 @@ struct TfJobRun {
         if (row < L) {
           char* img = smem + TF_A1B + par * 2 * TF_PA + TF_PA;
           *(f32x4*)(img + (row + HALO) * TF_RSB + (OOFF + chb) * 4) = p[mt];
-          if constexpr (TRAIN) A.amax[(R0 + (unsigned)row) * 32u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)code[mt];
+          if constexpr (TRAIN && !(TFV & 32)) A.amax[(R0 + (unsigned)row) * 32u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)code[mt];
         }
       }
     }
@@ -382,7 +406,7 @@ struct TfJobRun {
 template <int EM, bool TRAIN, bool DROP>
 struct TfJobRun<EM, TRAIN, TNone, DROP> {
   __device__ __forceinline__ void init(const TfArgs&, char*, int, int) {}
-  __device__ __forceinline__ void run(const TfArgs&, char*, int, unsigned, int) const {}
+  __device__ __forceinline__ void run(const TfArgs&, char*, int, unsigned, int, int = 0, int = 0) const {}
 };
 
 // x planes (and Flipout sign words) of the next windows: global -> registers (one step ahead) -> LDS
@@ -480,23 +504,29 @@ __device__ __forceinline__ void tf_role(const TfArgs& A, char* smem, int s, int 
   // row indices fit 32 bits (the host refuses launches whose planes exceed 4 GiB)
   const unsigned Rs = (unsigned)(((long)s * A.B + split) * A.L), Rstep = (unsigned)(A.nsplit * A.L);
   for (int t = 0; t < nsteps; ++t) {
+    TF_STAMP_AT(A.dbg, t, 0);
     if constexpr (LOADER) {
       if (t + 1 < nwin) ld.put(smem, t + 1, lane);
       if (t + 2 < nwin) ld.fetch();
     }
+    TF_STAMP_AT(A.dbg, t, 1);
     {
       const int k = t - tfj_stage<J0>();
-      if (J0::layer >= 0 && k >= 0 && k < nwin) r0.run(A, smem, k, Rs + k * Rstep, lane);
+      if (J0::layer >= 0 && k >= 0 && k < nwin) r0.run(A, smem, k, Rs + k * Rstep, lane, t, 2);
     }
+    TF_STAMP_AT(A.dbg, t, 3);
     {
       const int k = t - tfj_stage<J1>();
-      if (J1::layer >= 0 && k >= 0 && k < nwin) r1.run(A, smem, k, Rs + k * Rstep, lane);
+      if (J1::layer >= 0 && k >= 0 && k < nwin) r1.run(A, smem, k, Rs + k * Rstep, lane, t, 4);
     }
+    TF_STAMP_AT(A.dbg, t, 5);
     {
       const int k = t - tfj_stage<J2>();
-      if (J2::layer >= 0 && k >= 0 && k < nwin) r2.run(A, smem, k, Rs + k * Rstep, lane);
+      if (J2::layer >= 0 && k >= 0 && k < nwin) r2.run(A, smem, k, Rs + k * Rstep, lane, t, 6);
     }
+    TF_STAMP_AT(A.dbg, t, 7);
     lds_barrier();
+    TF_STAMP_AT(A.dbg, t, 8);
   }
 }
 

@@ -438,8 +438,10 @@ __global__ void prep_weights_kernel(const PrepArgs A) {
 // C, Lw are template parameters: the index arithmetic is divisions by them (by a run-time value: ~40 instructions each,
 // and the kernel was bound by exactly that).
 enum { PF_TN = 16, PF_TC = 8 };
-template <int C, int Lw>
+template <class P, int C, int Lw>
 __device__ __forceinline__ void prep_flat_dense_body(const PrepArgs& A, int layer_id, int site, int tile_blk, int s) {
+  typedef typename std::conditional<P::BF, u16, float>::type elem_t;   // image element: bf16 (hi [+ lo]) or fp32
+  constexpr int EPV = 16 / (int)sizeof(elem_t);                        // elements per 16-byte store
   extern __shared__ __attribute__((aligned(16))) char pf_smem[];
   const LayerDesc ly = A.layers[layer_id];
   constexpr int ncg = C / PF_TC;
@@ -450,8 +452,8 @@ __device__ __forceinline__ void prep_flat_dense_body(const PrepArgs& A, int laye
   const bool radial = (A.mode == 3);
   const bool want_kl = mean_pass || (A.mode == 0 && s == 0);
   constexpr int run = PF_TC * Lw, tile = PF_TN * run;
-  u16* th = (u16*)pf_smem;
-  u16* tl = th + tile;
+  elem_t* th = (elem_t*)pf_smem;
+  elem_t* tl = th + tile;   // (bf16 only: the lo plane)
   const long off = A.T.site[site].off;
   float rr = 1.f;
   if (radial) rr = A.rad_r[s * A.T.n_sites + site] / A.norms[s * A.T.n_sites + site];
@@ -496,28 +498,48 @@ __device__ __forceinline__ void prep_flat_dense_body(const PrepArgs& A, int laye
       const float t1 = ((mu - A.prior_loc) / A.prior_scale) * ((mu - A.prior_loc) / A.prior_scale);
       acc += 0.5 * ((double)vr + (double)t1 - 1.0 - (double)logf(vr));
     }
-    const u16 h = f2bf(v);
     const int o = nl * run + l * PF_TC + cl;
-    th[o] = h;
-    tl[o] = f2bf(v - bf2f(h));
+    if constexpr (P::BF) {
+      const u16 h = f2bf(v);
+      th[o] = h;
+      tl[o] = f2bf(v - bf2f(h));
+    } else {
+      th[o] = v;
+    }
   }
   __syncthreads();
   // destinations: Flipout particle pass -> slot B (single bf16); mean pass -> the shared slot A; normal / radial -> slot A of s
-  u16 *d_hi, *d_lo, *d_t;
+  elem_t *d_hi, *d_lo, *d_t;
   if (A.mode == 2 && !mean_pass) {
-    d_hi = (u16*)A.b + A.slot_stride * s; d_lo = nullptr; d_t = (u16*)A.bt + A.slott_stride * s;
+    d_hi = (elem_t*)A.b + A.slot_stride * s; d_lo = nullptr; d_t = (elem_t*)A.bt + A.slott_stride * s;
   } else if (mean_pass) {
-    d_hi = (u16*)A.a_hi; d_lo = (u16*)A.a_lo; d_t = (u16*)A.at;
+    d_hi = (elem_t*)A.a_hi; d_lo = (elem_t*)A.a_lo; d_t = (elem_t*)A.at;
   } else {
-    d_hi = (u16*)A.a_hi + A.slot_stride * s; d_lo = (u16*)A.a_lo + A.slot_stride * s; d_t = (u16*)A.at + A.slott_stride * s;
+    d_hi = (elem_t*)A.a_hi + A.slot_stride * s; d_lo = P::BF ? (elem_t*)A.a_lo + A.slot_stride * s : nullptr; d_t = (elem_t*)A.at + A.slott_stride * s;
   }
-  for (int u = tid; u < PF_TN * Lw; u += 256) {
-    const int nl = u / Lw, l = u - nl * Lw;
-    const long fi = ly.w_off + (long)(n0 + nl) * ly.KP + (long)l * C + c0;
-    *(uint4*)(d_hi + fi) = *(const uint4*)(th + nl * run + l * PF_TC);
-    if (d_lo) *(uint4*)(d_lo + fi) = *(const uint4*)(tl + nl * run + l * PF_TC);
+  constexpr int FV = PF_TC / EPV;   // 16-byte pieces of a forward row's 8 channels
+  for (int u = tid; u < PF_TN * Lw * FV; u += 256) {
+    const int piece = u % FV, r = u / FV;
+    const int nl = r / Lw, l = r - nl * Lw;
+    const long fi = ly.w_off + (long)(n0 + nl) * ly.KP + (long)l * C + c0 + piece * EPV;
+    *(uint4*)(d_hi + fi) = *(const uint4*)(th + nl * run + l * PF_TC + piece * EPV);
+    if constexpr (P::BF) {
+      if (d_lo) *(uint4*)(d_lo + fi) = *(const uint4*)(tl + nl * run + l * PF_TC + piece * EPV);
+    }
   }
-  if (A.want_t) {
+  if constexpr (!P::BF) {
+    if (A.want_t) {
+      for (int u = tid; u < run * 4; u += 256) {
+        const int quarter = u & 3, q = u >> 2;   // q = l * TC + cl
+        const int l = q / PF_TC, cl = q - l * PF_TC;
+        f32x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = th[(quarter * 4 + j) * run + q];
+        const long ti = ly.wt_off + (long)(l * C + c0 + cl) * ly.KPt + n0 + quarter * 4;
+        *(f32x4*)(d_t + ti) = w;
+      }
+    }
+  } else if (A.want_t) {
     for (int u = tid; u < run * 2; u += 256) {
       const int half = u & 1, q = u >> 1;   // q = l * TC + cl
       const int l = q / PF_TC, cl = q - l * PF_TC;
@@ -543,10 +565,10 @@ __device__ __forceinline__ void prep_flat_dense_body(const PrepArgs& A, int laye
 // One launch for both: workgroups [0, n_tiles * ny) are (tile, particle) pairs of the wide dense layer, the rest walk the
 // remaining elements one thread each (two launches of ~15 us of mostly latency each were slower than the single
 // one-thread-per-element launch they replaced; side by side they are not).
-template <int C, int Lw>
+template <class P, int C, int Lw>
 __global__ __launch_bounds__(256) void prep_fused_kernel(const PrepArgs A, int layer_id, int site, unsigned n_tiles, unsigned ny) {
-  if (blockIdx.x < n_tiles * ny) prep_flat_dense_body<C, Lw>(A, layer_id, site, (int)(blockIdx.x % n_tiles), (int)(blockIdx.x / n_tiles));
-  else prep_weights_body<PrecBF>(A, blockIdx.x - n_tiles * ny);
+  if (blockIdx.x < n_tiles * ny) prep_flat_dense_body<P, C, Lw>(A, layer_id, site, (int)(blockIdx.x % n_tiles), (int)(blockIdx.x / n_tiles));
+  else prep_weights_body<P>(A, blockIdx.x - n_tiles * ny);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -25,7 +25,6 @@
 #define TR_SWAP 0
 #endif
 #include "kernels_conv_bf.h"
-#include "kernels_conv_dx.h"   // rot16
 
 enum { TR_NC = 11, TR_NW = 12, TR_THREADS = TR_NW * 64 };
 enum {

@@ -16,7 +16,6 @@
 #include "kernels_group.h"
 #include "kernels_misc.h"
 #include "kernels_conv_bf.h"
-#include "kernels_conv_dx.h"
 #include "kernels_dense_fwd.h"
 #include "kernels_trunk.h"
 #include "kernels_trunk_bwd.h"
@@ -512,6 +511,9 @@ extern "C" int bnn_plan_create(const BnnPlanDesc* desc, BnnPlan** out) {
   if (desc->mode < 0 || desc->mode > 3) return fail(BNN_E_INVALID, "unknown mode %d", desc->mode);
   if (desc->prec != BNN_PREC_F32 && desc->prec != BNN_PREC_BF16X3) return fail(BNN_E_INVALID, "unknown prec %d", desc->prec);
   if (desc->max_particles < 1 || desc->max_batch < 1) return fail(BNN_E_INVALID, "max_particles / max_batch must be >= 1");
+  if (desc->mode == BNN_MODE_LRT && desc->prec == BNN_PREC_BF16X3 && desc->net == BNN_NET_INCEPTION)
+    return fail(BNN_E_INVALID, "LRT on the Inception net is implemented on the exact-fp32 plan (BNN_PREC_F32); the split-bf16 plan "
+                               "covers Flipout, radial and plain sampling there, and the Linear net's LRT");
   BnnPlan* p = new BnnPlan();
   p->d = *desc;
   p->cap_windows = desc->max_windows > 0 ? desc->max_windows : (long)desc->max_particles * desc->max_batch;
@@ -647,6 +649,9 @@ static int make_ctx(BnnPlan* p, const BnnElboArgs* a, const BnnNoise* nz, void* 
   if (c->mode < 0 || c->mode > 3) return fail(BNN_E_INVALID, "bad mode %d", c->mode);
   c->em = em_of(c->mode);
   c->radial = c->mode == BNN_MODE_RADIAL;
+  if (c->em == EM_LRT && p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION)
+    return fail(BNN_E_INVALID, "LRT on the Inception net is implemented on the exact-fp32 plan (BNN_PREC_F32); the split-bf16 plan "
+                               "covers Flipout, radial and plain sampling there, and the Linear net's LRT");
   c->S = a->particles;
   c->B = a->batch;
   c->train = train;
@@ -831,9 +836,10 @@ static int do_sample(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
   A.prior_loc = (float)a->prior_loc;
   A.prior_scale = (float)a->prior_scale;
   ProfScope ps_(&p->prof, PK_SAMPLE, 0, c->st);
-  // the wide dense layer behind nn.Flatten goes through the tile kernel (16-byte image stores instead of 2-byte ones)
+  // the wide dense layer behind nn.Flatten goes through the tile kernel (16-byte image stores instead of 2- / 4-byte ones)
   int flat_layer = -1;
-  if (p->d.prec == BNN_PREC_BF16X3 && c->mode != BNN_MODE_LRT)
+  const bool bfp = p->d.prec == BNN_PREC_BF16X3;
+  if (c->mode != BNN_MODE_LRT)
     for (int i = 0; i < p->n_layers; ++i) {
       const LayerDesc& l = p->layers[i];
       if (!l.is_conv && l.taps == 1 && l.cmap == CM_FLATTEN && l.cmap_a % PF_TC == 0 && l.cout % PF_TN == 0 &&
@@ -846,11 +852,12 @@ static int do_sample(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
     const SiteDesc& sd = p->ptab.site[l.site_w];
     A.skip_lo = sd.off;
     A.skip_hi = sd.off + sd.numel;
-    const int lds = 2 * PF_TN * PF_TC * l.cmap_b * 2;
+    const int lds = bfp ? 2 * PF_TN * PF_TC * l.cmap_b * 2 : PF_TN * PF_TC * l.cmap_b * 4;
     const unsigned tiles = (unsigned)((l.cout / PF_TN) * (l.cmap_a / PF_TC));
     const unsigned ny = (unsigned)(c->S + (c->mode == BNN_MODE_FLIPOUT ? 1 : 0));
     const unsigned rest = (unsigned)((p->P - sd.numel + 255) / 256);
-    prep_fused_kernel<80, 30><<<dim3(tiles * ny + rest), dim3(256), lds, c->st>>>(A, flat_layer, l.site_w, tiles, ny);
+    if (bfp) prep_fused_kernel<PrecBF, 80, 30><<<dim3(tiles * ny + rest), dim3(256), lds, c->st>>>(A, flat_layer, l.site_w, tiles, ny);
+    else prep_fused_kernel<PrecF32, 80, 30><<<dim3(tiles * ny + rest), dim3(256), lds, c->st>>>(A, flat_layer, l.site_w, tiles, ny);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -901,11 +908,6 @@ static void fill_group_args(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, int 
     A->t[t + T_Q] = tens_ref(p, t, 2);
   }
   A->t[T_X] = TensorRef{const_cast<float*>(x), nullptr, p->x_ctot, TF_F32};
-  if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION) {
-    // the conv kernels read the windows as bf16 hi/lo planes [B*L][32] (built by x_planes_kernel)
-    char* xp = (char*)p->bufs.workspace + p->o_xplanes;
-    A->t[T_X] = TensorRef{xp, xp + (size_t)p->d.max_batch * p->d.win_length * 32 * 2, 32, TF_BF16};
-  }
   A->t[T_POOLGRAD] = TensorRef{ws_f(p, p->o_poolgrad), nullptr, 128, p->d.prec == BNN_PREC_BF16X3 ? TF_BF16 : TF_F32};
   A->amax = nullptr;
   if (p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION && c->train)   // no backward, no codes (evaluate / predict)
@@ -999,224 +1001,12 @@ static int launch_dw(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int 
   return 0;
 }
 
-// ---- bf16-plane kernels of the conv groups and the dense layers (kernels_conv_bf.h, kernels_conv_dx.h, kernels_dense_fwd.h) ----
-// jobs of the role-specialised forward (one per compute wave): tiles whose K exceeds FW_KS k-steps
-// are split, then the longest jobs keep being split until all `nc` compute waves have work.
-// `mask` selects the branches of this workgroup kind.
-static int build_conv_fwd2_jobs(const GroupArgs& A, const LayerDesc* layers, unsigned mask, int nc, FwdJob* job,
-                                int* has_pool, int* n_red) {
-  for (int w = 0; w < FW_NC; ++w) job[w].b = -1;
-  *has_pool = 0;
-  struct Tile { int b, nt, ks, nm; };
-  std::vector<Tile> tiles;
-  int njobs = 0;
-  for (int b = 0; b < A.g.n_branch; ++b) {
-    if (!(mask & (1u << b))) continue;
-    const BranchDesc& br = A.g.br[b];
-    const LayerDesc& ly = layers[br.layer];
-    if (br.pool) *has_pool = 1;
-    const int ks = (ly.taps * (br.cin_p / 8) + 3) / 4;
-    for (int n = 0; n < br.ntiles; ++n) {
-      const int nm = (ks + FW_KS - 1) / FW_KS;
-      tiles.push_back({b, n, ks, nm});
-      njobs += nm;
-    }
-  }
-  if (njobs > nc) return 1;   // does not fit: caller falls back
-  // optional splits only where a K-split reduction (one more barrier per window) is needed anyway
-  bool any_split = false;
-  for (const Tile& t : tiles) any_split |= t.nm > 1;
-  // keep splitting the longest job while it has more than 2 k-steps (measured optimum on the block-2 k3/k5 group:
-  // finer splits cost more in the LDS reduction than they save in MFMAs)
-  const double fill_thr = 2.0;
-  while (any_split && njobs < nc) {
-    int best = -1;
-    double bv = fill_thr;
-    for (size_t t = 0; t < tiles.size(); ++t) {
-      const double v = (double)tiles[t].ks / tiles[t].nm;
-      if (v > bv && tiles[t].nm < tiles[t].ks) { bv = v; best = (int)t; }
-    }
-    if (best < 0) break;
-    tiles[best].nm++;
-    njobs++;
-  }
-  int w = 0, ngrp = 0;
-  for (size_t t = 0; t < tiles.size(); ++t) {
-    for (int m = 0; m < tiles[t].nm; ++m, ++w) {
-      FwdJob& J = job[w];
-      J.b = (signed char)tiles[t].b;
-      J.nt = (signed char)tiles[t].nt;
-      J.ks0 = (signed char)(tiles[t].ks * m / tiles[t].nm);
-      J.ks1 = (signed char)(tiles[t].ks * (m + 1) / tiles[t].nm);
-      J.grp = tiles[t].nm > 1 ? (signed char)t : -1;
-      J.owner = m == 0;
-      J.member = (signed char)m;
-      J.nmember = (signed char)tiles[t].nm;
-      if (J.ks1 - J.ks0 > FW_KS) return 1;
-    }
-    if (tiles[t].nm > 1) ngrp++;
-  }
-  *n_red = ngrp;
-  return 0;
-}
-
-template <int NC, int NL>
-static int launch_conv_fwd_dma_t(const GroupArgs& A, const ConvFwd2Plan& F, int em, int lds, unsigned grid, hipStream_t st) {
-  // the per-group conv kernels are the LRT path of the Inception net: every other estimator runs the fused trunk kernels
-  if (em != EM_LRT) return fail(BNN_E_INVALID, "per-group conv forward: estimator %d is covered by the trunk kernels", em);
-  BNN_DRY_RETURN();
-  BNN_TRY(set_lds(conv_fwd_dma_kernel<EM_LRT, NC, NL>, lds));
-  conv_fwd_dma_kernel<EM_LRT, NC, NL><<<dim3(grid), dim3((NC + NL) * 64), lds, st>>>(A, F);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-static int launch_conv_fwd_dma(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
-  GroupArgs A = A0;
-  ConvFwd2Plan F{};
-  const int c8n = A.g.in_cin_p / 8;
-  if (c8n != 4 && c8n != 16) return fail(BNN_E_INVALID, "conv fwd: input of %d channels (need 32 or 128)", A.g.in_cin_p);
-  if ((A.g.L * c8n + 63) / 64 * 2 > 16) return fail(BNN_E_INVALID, "conv fwd: window too large for the loader plan");
-  const int pbytes = IMG_ROWS * A.g.in_cin_p * 2;
-  {
-    // LDS-DMA geometry of a plane: ninst instructions of 64 lanes x 16 B land at rows [HALO, HALO + L); the counted
-    // vmcnt of a loader (its share of 2 planes x ninst, + the sign word) must stay inside the wait macro's range
-    const int nchunk = A.g.L * c8n, ninst = (nchunk + 63) / 64;
-    if (HALO * A.g.in_cin_p * 2 + nchunk * 16 > pbytes) return fail(BNN_E_INVALID, "conv fwd: a window overruns its LDS plane");
-    if ((2 * ninst + 1) / 2 + 1 > 12) return fail(BNN_E_INVALID, "conv fwd: %d DMA instructions per loader exceed the counted-wait range", ninst);
-    static_assert(FW_SLOTS >= 2 + 1, "two windows in flight need three slots");
-  }
-  // preferred: two workgroup kinds of 8 waves (6 compute + 2 loaders), two workgroups per CU
-  bool two = A.g.n_branch > 1;
-  if (two) {
-    // deal the branches: heaviest (k-steps x n-tiles) first onto the lighter kind
-    int wgt[BNN_MAX_BRANCH], order[BNN_MAX_BRANCH], load[2] = {0, 0};
-    unsigned mask[2] = {0, 0};
-    for (int b = 0; b < A.g.n_branch; ++b) {
-      const BranchDesc& br = A.g.br[b];
-      wgt[b] = br.ntiles * ((layers[br.layer].taps * (br.cin_p / 8) + 3) / 4);
-      order[b] = b;
-    }
-    std::sort(order, order + A.g.n_branch, [&](int x, int y) { return wgt[x] > wgt[y]; });
-    for (int i = 0; i < A.g.n_branch; ++i) {
-      const int k = load[1] < load[0] ? 1 : 0;
-      mask[k] |= 1u << order[i];
-      load[k] += wgt[order[i]];
-    }
-    F.nkinds = 2;
-    for (int k = 0; k < 2 && two; ++k)
-      if (build_conv_fwd2_jobs(A, layers, mask[k], 6, F.job[k], &F.has_pool[k], &F.n_red_groups[k])) two = false;
-    const int lds2 = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + 4096 + ((F.n_red_groups[0] | F.n_red_groups[1]) ? 6 * 4 * 256 * 4 : 0);
-    if (two && lds2 > 80 * 1024) two = false;   // two workgroups must fit one CU
-    if (two) {
-      F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
-      const unsigned grid = (unsigned)(2 * A.cg.S * F.nsplit);
-      ProfScope ps_(pf, PK_FWD, gi, st);
-      ps_.name("conv_fwd_dma_kernel<%d, 6, 2>", em);
-      return launch_conv_fwd_dma_t<6, 2>(A, F, em, lds2, grid, st);
-    }
-  }
-  F = ConvFwd2Plan{};
-  F.nkinds = 1;
-  if (build_conv_fwd2_jobs(A, layers, 0xffu, FW_NC, F.job[0], &F.has_pool[0], &F.n_red_groups[0]))
-    return fail(BNN_E_INVALID, "conv fwd plan: jobs exceed %d compute waves", FW_NC);
-  F.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
-  const int lds = (FW_SLOTS * 2 + 4) * pbytes + FW_SLOTS * 64 * 4 + 4096 + (F.n_red_groups[0] > 0 ? FW_NC * 4 * 256 * 4 : 0);
-  const unsigned grid = (unsigned)(A.cg.S * F.nsplit);
-  ProfScope ps_(pf, PK_FWD, gi, st);
-  ps_.name("conv_fwd_dma_kernel<%d, %d, %d>", em, (int)FW_NC, (int)FW_NL);
-  return launch_conv_fwd_dma_t<FW_NC, FW_NL>(A, F, em, lds, grid, st);
-}
-
-static void build_conv_dw_plan(const GroupArgs& A, const LayerDesc* layers, ConvDwPlan* D) {
-  *D = ConvDwPlan{};
-  int zo = 0, nt = 0;
-  for (int b = 0; b < A.g.n_branch; ++b) {
-    const BranchDesc& br = A.g.br[b];
-    const LayerDesc& ly = layers[br.layer];
-    D->zoff[b] = zo;
-    zo += (br.cout + 15) & ~15;
-    if (br.pool) D->has_pool = 1;
-    const int ctiles = (br.cin_p + 15) / 16;
-    for (int n = 0; n < br.ntiles; ++n)
-      for (int t = 0; t < ly.taps; ++t)
-        for (int c = 0; c < ctiles; ++c) {
-          DwTile T;
-          T.b = (signed char)b; T.nt = (signed char)n; T.tap = (signed char)t; T.ct = (signed char)c;
-          D->tile[nt++] = T;
-        }
-  }
-  D->ntiles = nt;
-  D->zw = zo;
-}
-
-// The per-group conv dW kernel is the LRT path of the Inception net (the trunk kernels cover the other estimators).
-// Instantiations: <EM_LRT, 4 or 6 tiles per wave, 1 window per iteration, 8 waves> - the ones that fit the register file
-// (-Rpass-analysis=kernel-resource-usage: 0 bytes of scratch).  A group with more than 48 tiles is launched twice over
-// halves of its tile list; the second launch skips the bias sums.
-static int launch_conv_dw_mw_lrt(const GroupArgs& A, const ConvDwPlan& D, int lds, unsigned grid, hipStream_t st) {
-  BNN_DRY_RETURN();
-  const int tpw = (D.ntiles + CV_WAVES - 1) / CV_WAVES;
-  if (tpw <= 4) {
-    BNN_TRY(set_lds(conv_dw_mw_kernel<EM_LRT, 4, 1, 8>, lds));
-    conv_dw_mw_kernel<EM_LRT, 4, 1, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
-  } else if (tpw <= 6) {
-    BNN_TRY(set_lds(conv_dw_mw_kernel<EM_LRT, 6, 1, 8>, lds));
-    conv_dw_mw_kernel<EM_LRT, 6, 1, 8><<<dim3(grid), dim3(CV_THREADS), lds, st>>>(A, D);
-  } else {
-    return fail(BNN_E_INVALID, "conv dW: %d tiles per wave", tpw);
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
+// ---- bf16-plane kernels of the dense layers (kernels_conv_bf.h, kernels_dense_fwd.h) ----
 static int check_slab_slots(const BnnPlan* p, const Ctx* c, int g, int nsplit) {
   if ((long)c->S * nsplit > p->slab_slots[g])
     return fail(BNN_E_INVALID, "dW partial images: %d particles x %d splits exceed the %d slabs of this plan", c->S, nsplit, p->slab_slots[g]);
   return 0;
 }
-// partial images ("slabs") for the per-group conv dW kernels of the Inception net: the trunk kernels' workspace and layout
-static bool conv_dw_slabs(const BnnPlan* p, int gi) { return p->slab_stride > 0 && p->d.prec == BNN_PREC_BF16X3 && p->d.net == BNN_NET_INCEPTION && gi < 3; }
-static int conv_dw_nsplit(const Ctx* c) { return std::max(1, std::min(c->B, 256 / std::max(1, c->S))); }
-
-static int launch_conv_dw_mw(BnnPlan* p, const Ctx* c_for_slabs, const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
-  GroupArgs A = A0;
-  if (em != EM_LRT) return fail(BNN_E_INVALID, "per-group conv dW: estimator %d is covered by the trunk kernels", em);
-  static thread_local ConvDwPlan D, H;
-  build_conv_dw_plan(A, layers, &D);
-  if (D.ntiles > 96) return fail(BNN_E_INVALID, "conv dW plan too large");
-  if (A.g.in_cin_p % 8 || D.zw % 8) return fail(BNN_E_INVALID, "conv dW: channel counts must be multiples of 8");
-  if (A.g.L * (A.g.in_cin_p / 8) > CV_THREADS || A.g.L * (D.zw / 8) > 2 * CV_THREADS)
-    return fail(BNN_E_INVALID, "conv dW staging plan exceeds the compiled unit counts");
-  D.nsplit = std::max(1, std::min(A.cg.B, 256 / std::max(1, A.cg.S)));
-  if (conv_dw_slabs(p, gi)) {
-    BNN_TRY(check_slab_slots(p, c_for_slabs, gi, D.nsplit));
-    D.slab_a = ws_f(p, p->o_slab_a[gi]);
-    D.slab_b = ws_f(p, p->o_slab_b[gi]);
-    D.slab_stride = p->slab_stride;
-  }
-  const int xw16 = rup(A.g.in_cin_p, 16);
-  const int xbytes = (IMG_ROWS * img_row_stride(xw16, true) * 2 + 15) & ~15;
-  const int zbytes = (IMG_ROWS * img_row_stride(D.zw, true) * 2 + 15) & ~15;
-  const int wbytes = 2 * (xbytes + (D.has_pool ? xbytes : 0) + zbytes);
-  if (wbytes > 160 * 1024) return fail(BNN_E_INVALID, "conv dW: %d bytes of LDS per window", wbytes);
-  const int lds = wbytes;
-  const unsigned grid = (unsigned)(A.cg.S * D.nsplit);
-  const int parts = D.ntiles > 6 * CV_WAVES ? 2 : 1;
-  ProfScope ps_(pf, PK_DW, gi, st);
-  ps_.name("conv_dw_mw_kernel<1, %d, 1, 8>%s", (D.ntiles / parts + CV_WAVES - 1) / CV_WAVES <= 4 ? 4 : 6, parts == 2 ? " x2" : "");
-  if (parts == 1) return launch_conv_dw_mw_lrt(A, D, lds, grid, st);
-  const int half = (D.ntiles + 1) / 2;
-  for (int part = 0; part < 2; ++part) {
-    H = D;
-    H.ntiles = part == 0 ? half : D.ntiles - half;
-    for (int t = 0; t < H.ntiles; ++t) H.tile[t] = D.tile[part * half + t];
-    H.no_bias = part;
-    BNN_TRY(launch_conv_dw_mw_lrt(A, H, lds, grid, st));
-  }
-  return 0;
-}
-
 static int launch_dense_dw_bf(const GroupArgs& A0, int em, hipStream_t st, Prof* pf, int gi) {
   GroupArgs A = A0;
   const BranchDesc& br = A.g.br[0];
@@ -1231,137 +1021,6 @@ static int launch_dense_dw_bf(const GroupArgs& A0, int em, hipStream_t st, Prof*
   if (em == EM_PLAIN) dense_dw_bf_kernel<EM_PLAIN><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
   else if (em == EM_LRT) dense_dw_bf_kernel<EM_LRT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
   else dense_dw_bf_kernel<EM_FLIPOUT><<<dim3(grid), dim3(512), lds, st>>>(A, nchunk, nsplit);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-// fused conv dX (kernels_conv_dx.h): all branches of the group, pooled ones scattered in-kernel
-static int launch_conv_dx2(const GroupArgs& A0, const LayerDesc* layers, int em, hipStream_t st, Prof* pf, int gi) {
-  GroupArgs A = A0;
-  static thread_local ConvDx2Plan D;   // large; copied into the kernel arguments at launch
-  D = ConvDx2Plan{};
-  const int L = A.g.L, xw = A.g.in_cin_p;
-  const int npt = em == EM_LRT ? 3 : 2;
-  D.ntile = xw / 16;
-  // 8 tiles: one 10-wave workgroup kind (every slice loaded and masked once); narrow tensors: 6-wave kinds
-  const int nc = D.ntile > 4 ? 8 : 4;
-  const int nw = nc + DX2_NL;
-  D.nkinds = (D.ntile + nc - 1) / nc;
-  int zel = 0, units = 0;
-  int nkd = 0, nkp = 0;   // k-steps of the direct / pooled branches
-  signed char kb[2][DX2_KS], ki[2][DX2_KS];
-  D.dx_t = A.g.in_t + T_GRAD;
-  for (int b = 0; b < A.g.n_branch; ++b) {
-    const BranchDesc& br = A.g.br[b];
-    D.zbase[b] = -1;
-    if (br.dx_t < 0) continue;
-    const LayerDesc& ly = layers[br.layer];
-    if (br.cout % 8 || (16 % (br.cout / 8)) != 0) return fail(BNN_E_INVALID, "conv dX: branch cout %d unsupported", br.cout);
-    if (br.pool) D.has_pool = 1;
-    D.zbase[b] = zel;
-    zel += IMG_ROWS * br.cout;
-    units += L * (br.cout / 8);
-    const int ks = (ly.taps * (ly.cout_p8 / 8) + 3) / 4;
-    int& n = br.pool ? nkp : nkd;
-    for (int i = 0; i < ks; ++i) {
-      if (n >= DX2_KS) return fail(BNN_E_INVALID, "conv dX: more than %d k-steps", DX2_KS);
-      kb[br.pool ? 1 : 0][n] = (signed char)b;
-      ki[br.pool ? 1 : 0][n] = (signed char)i;
-      ++n;
-    }
-  }
-  const int nks = nkd + nkp;
-  // compiled k-step shapes: (5 direct, 1 pooled) and (5 direct, 0 pooled)
-  if (nkd > 5 || nkp > 1) return fail(BNN_E_INVALID, "conv dX: %d direct + %d pooled k-steps", nkd, nkp);
-  for (int i = 0; i < DX2_KS; ++i) D.ks_b[i] = -1;
-  for (int i = 0; i < nkd; ++i) { D.ks_b[i] = kb[0][i]; D.ks_i[i] = ki[0][i]; }
-  for (int i = 0; i < nkp; ++i) { D.ks_b[5 + i] = kb[1][i]; D.ks_i[5 + i] = ki[1][i]; }
-  if (nks == 0) return 0;
-  if (units > DX2_MU * nw * 64) return fail(BNN_E_INVALID, "conv dX: mask pass needs %d units", units);
-  if (D.has_pool && (!A.amax || (xw % 16) != 0 || ((xw / 16) & (xw / 16 - 1)) != 0))
-    return fail(BNN_E_INVALID, "conv dX: pooled branch without an arg-max plane");
-  if ((xw / 8) & (xw / 8 - 1)) return fail(BNN_E_INVALID, "conv dX: %d input channels", xw);
-  D.nks = nks;
-  D.zelems = zel;
-  const int zbytes = zel * 2, xbytes = em == EM_LRT ? IMG_ROWS * xw * 2 : 0, abytes = D.has_pool ? IMG_ROWS * xw : 0;
-  D.o_x = npt * zbytes;
-  D.o_am = D.o_x + xbytes;
-  D.slot_bytes = (D.o_am + abytes + 15) & ~15;
-  auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
-  int ni = 0;
-  auto add_stream = [&](const void* base, uint32_t wstride, uint32_t rstride, int cb, int sh, uint32_t dst) -> int {
-    const int n = L * cb;
-    for (int q0 = 0; q0 < n; q0 += 64) {
-      if (ni >= DX2_MAXI) return fail(BNN_E_INVALID, "conv dX: DMA table overflow");
-      Dx2Inst& I = D.inst[ni++];
-      I.base = base;
-      I.wstride = wstride;
-      I.rstride = rstride;
-      I.dst = dst + (uint32_t)q0 * 16u;
-      I.geom = (uint32_t)q0 | ((uint32_t)ilog2(cb) << 16) | ((uint32_t)sh << 24);
-      I.qn = (uint32_t)n;
-    }
-    return 0;
-  };
-  for (int pt = 0; pt < npt; ++pt)
-    for (int b = 0; b < A.g.n_branch; ++b) {
-      if (D.zbase[b] < 0) continue;
-      const BranchDesc& br = A.g.br[b];
-      if (pt == 1 && !br.relu) continue;
-      const TensorRef tt = pt == 0 ? A.t[br.out_t + T_GRAD] : (pt == 1 ? A.t[br.out_t] : A.t[br.q_t]);
-      if (!tt.p || tt.fmt != TF_BF16) return fail(BNN_E_INVALID, "conv dX: plane %d of branch %d is not bf16", pt, b);
-      const int cb = br.cout / 8;
-      BNN_TRY(add_stream((const char*)tt.p + (size_t)br.out_off * 2, (uint32_t)L * tt.ctot * 2, (uint32_t)tt.ctot * 2, cb,
-                         cb >= 16 ? 0 : ilog2(16 / cb), (uint32_t)(pt * zbytes + (D.zbase[b] + HALO * br.cout) * 2)));
-    }
-  if (em == EM_LRT) {
-    const TensorRef tin = A.t[A.g.in_t];
-    BNN_TRY(add_stream(tin.p, (uint32_t)L * tin.ctot * 2, (uint32_t)tin.ctot * 2, xw / 8, 0, (uint32_t)(D.o_x + HALO * xw * 2)));
-  }
-  if (D.has_pool)
-    BNN_TRY(add_stream(A.amax, (uint32_t)L * xw, (uint32_t)xw, xw / 16, 0, (uint32_t)(D.o_am + HALO * xw)));
-  D.ninst = ni;
-  for (int i = 0; i < ni; ++i) {   // every DMA instruction lands inside the slot
-    const Dx2Inst& I = D.inst[i];
-    const uint32_t q0 = I.geom & 0xffffu, lanes = std::min<uint32_t>(64u, I.qn - q0);
-    if (I.dst + lanes * 16u > (uint32_t)D.slot_bytes) return fail(BNN_E_INVALID, "conv dX: DMA instruction %d overruns its slot", i);
-  }
-  if ((ni + DX2_NL - 1) / DX2_NL + 1 > 49) return fail(BNN_E_INVALID, "conv dX: %d DMA instructions per window", ni);
-  // slots: 3 (two windows ahead) if two workgroups still share a CU, else 2 if that makes them fit
-  const int extra = 4096;
-  auto total = [&](int ns) { return ns * D.slot_bytes + ns * 256 + extra; };
-  int wg_per_cu = 2;
-  if (nc == 8) {   // 10 waves of ~146 registers: one workgroup per CU
-    wg_per_cu = 1;
-    D.nslots = total(3) <= 160 * 1024 ? 3 : 2;
-  } else if (total(3) <= 80 * 1024) D.nslots = 3;
-  else if (total(2) <= 80 * 1024) D.nslots = 2;
-  else {
-    wg_per_cu = 1;
-    D.nslots = total(3) <= 160 * 1024 ? 3 : 2;
-  }
-  const int lds = total(D.nslots);
-  if (D.nslots < 2 || (D.nslots - 2) * ((ni + DX2_NL - 1) / DX2_NL + 1) > 49)
-    return fail(BNN_E_INVALID, "conv dX: %d slots / %d DMA instructions exceed the counted-wait range", D.nslots, ni);
-  if (lds > 160 * 1024) return fail(BNN_E_INVALID, "conv dX: %d bytes of LDS", lds);
-  D.nsplit = std::max(1, std::min(A.cg.B, (256 * wg_per_cu) / std::max(1, A.cg.S * D.nkinds)));
-  const unsigned grid = (unsigned)(A.cg.S * D.nsplit * D.nkinds);
-  ProfScope ps_(pf, PK_DX, gi, st);
-  ps_.name("conv_dx2_kernel<%d, 5, %d, %d>", em, nkp, nc);
-#define LAUNCH_DX2(EMV, KPV)                                                                   \
-  do {                                                                                         \
-    if (nc == 8) {                                                                             \
-      BNN_TRY(set_lds(conv_dx2_kernel<EMV, 5, KPV, 8>, lds));                                  \
-      conv_dx2_kernel<EMV, 5, KPV, 8><<<dim3(grid), dim3(nw * 64), lds, st>>>(A, D);           \
-    } else {                                                                                   \
-      BNN_TRY(set_lds(conv_dx2_kernel<EMV, 5, KPV, 4>, lds));                                  \
-      conv_dx2_kernel<EMV, 5, KPV, 4><<<dim3(grid), dim3(nw * 64), lds, st>>>(A, D);           \
-    }                                                                                          \
-  } while (0)
-  if (em != EM_LRT) return fail(BNN_E_INVALID, "per-group conv dX: estimator %d is covered by the trunk kernels", em);
-  BNN_DRY_RETURN();
-  if (nkp) LAUNCH_DX2(EM_LRT, 1); else LAUNCH_DX2(EM_LRT, 0);
-#undef LAUNCH_DX2
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1915,6 +1574,21 @@ static int launch_tf_fwd(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const f
     tf_fwd_kernel<EMV, TRV><<<dim3(grid), dim3(TF_THREADS), TF_LDS, c->st>>>(T);          \
   } while (0)
   BNN_DRY_RETURN();
+#if TF_STAMPS
+  static unsigned long long* tf_dbg = nullptr;   // diagnostics build: stamps of the last launch -> gpurun_out/tf_stamps.bin
+  const size_t tf_dbg_bytes = 8 * 48 * 16 * sizeof(unsigned long long);
+  if (!tf_dbg) HIP_TRY(hipMalloc((void**)&tf_dbg, tf_dbg_bytes));
+  HIP_TRY(hipMemsetAsync(tf_dbg, 0, tf_dbg_bytes, c->st));
+  T.dbg = tf_dbg;
+  struct TfDbgDump {
+    unsigned long long* d; size_t n; hipStream_t st;
+    ~TfDbgDump() {
+      std::vector<char> h(n);
+      if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(h.data(), d, n, hipMemcpyDeviceToHost) != hipSuccess) return;
+      if (FILE* f = fopen("gpurun_out/tf_stamps.bin", "wb")) { fwrite(h.data(), 1, n, f); fclose(f); }
+    }
+  } tf_dbg_dump{tf_dbg, tf_dbg_bytes, c->st};
+#endif
   if (drop_on(c)) {
     T.drop_rate = (float)(c->drop->p / 4);
     T.drop_scale = (float)(1.0 / (1.0 - c->drop->p / 4));
@@ -1958,15 +1632,6 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
   }
   if (tf) BNN_TRY(launch_tf_fwd(p, a, c, x));
   else if (trunk) BNN_TRY(launch_trunk_fwd(p, a, c, x));
-  if (bf && p->d.net == BNN_NET_INCEPTION && !trunk) {
-    const long rows = (long)c->B * p->d.win_length;
-    u16* xh = (u16*)((char*)p->bufs.workspace + p->o_xplanes);
-    u16* xl = xh + (size_t)p->d.max_batch * p->d.win_length * 32;
-    if (!g_dry) {
-      x_planes_kernel<<<dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, c->st>>>(x, xh, xl, rows, p->d.n_features, 32);
-      HIP_TRY(hipGetLastError());
-    }
-  }
   for (int gi = trunk ? 3 : 0; gi < p->n_groups; ++gi) {
     GroupArgs A;
     fill_group_args(p, a, c, gi, x, &A);
@@ -1979,7 +1644,7 @@ static int do_forward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c, const floa
     else if (!bf)
       BNN_TRY(launch_fwd<PrecF32>(A, c->em, c->st, &p->prof, gi));
     else if (!A.g.is_dense)
-      BNN_TRY(launch_conv_fwd_dma(A, p->layers, c->em, c->st, &p->prof, gi));
+      return fail(BNN_E_INVALID, "internal: a conv group of the split-bf16 plan outside the fused trunk kernels");
     else if (dense_ks_ok(p, A, c->em)) {
       const bool fl = last_fused_ok(p, c->em, gi);
       BNN_TRY(launch_dense_ks_fwd(p, A, c->em, c->st, &p->prof, gi, fl));
@@ -2517,10 +2182,7 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     if (p->d.prec == BNN_PREC_F32)
       BNN_TRY((launch_dw<PrecF32, 2>(A, c->em, c->st, &p->prof, gi)));
     else if (!A.g.is_dense)
-      {
-      BNN_TRY(launch_conv_dw_mw(p, c, A, p->layers, c->em, c->st, &p->prof, gi));
-      if (gi == 0 && conv_dw_slabs(p, 0)) BNN_TRY(reduce_trunk_slabs(p, c));
-    }
+      return fail(BNN_E_INVALID, "internal: a conv group of the split-bf16 plan outside the fused trunk kernels");
     else if (A.g.n_branch == 1 && !A.g.in_bcast && A.g.br[0].cout <= 64 && (A.g.br[0].cout % 8) == 0 &&
              (A.g.br[0].cin_p % 16) == 0 && A.g.br[0].cin_real == A.g.br[0].cin_p && A.t[A.g.in_t].fmt == TF_BF16 &&
              (A.t[A.g.in_t].ctot % 8) == 0 && (A.t[A.g.br[0].out_t].ctot % 8) == 0 && A.t[A.g.br[0].out_t].fmt == TF_BF16)
@@ -2531,12 +2193,6 @@ static int do_backward(BnnPlan* p, const BnnElboArgs* a, const Ctx* c) {
     for (int b = 0; b < A.g.n_branch; ++b) {
       if (A.g.br[b].dx_t < 0) continue;
       (A.g.br[b].pool ? any_pool : any_direct) = true;
-    }
-    const bool conv_bf = p->d.prec == BNN_PREC_BF16X3 && !A.g.is_dense;
-    if (conv_bf && (any_direct || any_pool)) {
-      // one launch: direct and pooled branches, arg-max scatter included
-      BNN_TRY(launch_conv_dx2(A, p->layers, c->em, c->st, &p->prof, gi));
-      continue;
     }
     if (any_direct) {
       if (p->d.prec == BNN_PREC_F32)
@@ -2579,13 +2235,12 @@ static int reduce_trunk_slabs(BnnPlan* p, const Ctx* c) {
   const bool f32p = p->d.prec == BNN_PREC_F32;
   for (int which = 0; which < 4; ++which) {   // 0: slot A, 1: slot B (Flipout's dW | LRT's sigma^2 part), 2: bias sums, 3: LRT's sigma_b^2 sums
     if (which == 1 && c->em == EM_PLAIN) continue;
-    if (which == 2 && c->em == EM_LRT && !f32p) continue;   // the per-group bf16 LRT kernels add their bias sums with atomics
     if (which == 3 && !(c->em == EM_LRT && f32p)) continue;
     SlabReduceArgs& R = J.job[nj++];
     R = SlabReduceArgs{};
     for (int g = 0; g < 3; ++g) {
       R.slab[g] = ws_f(p, which == 0 ? p->o_slab_a[g] : (which == 1 ? p->o_slab_b[g] : (which == 2 ? p->o_slab_ba[g] : p->o_slab_bb)));
-      R.n[g] = p->d.prec == BNN_PREC_F32 ? tf_nsplit(c) : (c->em == EM_LRT ? conv_dw_nsplit(c) : trunk_dw_nsplit(c, g));
+      R.n[g] = p->d.prec == BNN_PREC_F32 ? tf_nsplit(c) : trunk_dw_nsplit(c, g);
     }
     R.stride = which >= 2 ? p->slab_bstride : p->slab_stride;
     for (int l = 0; l < 10; ++l) R.lay_end[l] = which >= 2 ? p->layers[l + 1].bias_off : p->layers[l + 1].w_off;

@@ -327,7 +327,7 @@ def main():
         nmed = 200 if not predict else 20
         companions["median"] = {"timed_steps": nmed, "ms_per_step": median_ms(one_step, nmed)}
         companions["median"]["value"] = S * B / (companions["median"]["ms_per_step"] * 1e-3)
-        if not predict:
+        if not predict and not (wl["net"] == "inception" and wl["fit_context"] == "lrt"):   # (LRT / Inception: fp32 plan only)
             # the other precision plan of the same workload: the judged line is the exact-fp32 plan (the reference trains in
             # fp32); the split-bf16 plan is the fast, narrower alternative
             other = "bf16x3" if args.prec == "f32" else "f32"

@@ -3,7 +3,7 @@
 # WRITE_SIZE passes), SQ counters (two passes).  Raw output under gpurun_out/ (scratch); `python profiles/make_summary.py
 # <tag>` turns it into the committed files under profiles/.
 WL=${1:-flipout_conv_s10}
-PREC=${2:-f32}   # pass bf16x3 for the split-bf16 plan (the LRT workloads have no fused fp32 kernels)
+PREC=${2:-f32}   # pass bf16x3 for the split-bf16 plan (lrt_linear_s1 runs on it)
 mkdir -p gpurun_out && cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/pmc_sq gpurun_out/pmc_sq2
 ARGS="--workload $WL --prec $PREC --no-cpu-baseline --no-companions"

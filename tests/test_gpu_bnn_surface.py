@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 
-def _model(guide="normal", ctx="lrt", S=1, prec="bf16x3", seed=0):
+def _model(guide="normal", ctx="lrt", S=1, prec="auto", seed=0):
     from bayesrul_amd.models.bayesian import BNN
     from bayesrul_amd.models.nets.inception import Inception
     torch.manual_seed(0)

@@ -42,10 +42,10 @@ def _setup(net, mode, prec, S, B, q_boost=1.0, seed=0):
 # bf16x3 plan, gradients against the f64 oracle (rel-L2): bounds = 2 x the values measured on MI355X (gpurun_out/
 # measured_errors.jsonl of the round-3 run, printed by tests.noise_util.record), per estimator: (d mu, d rho).  The backward
 # contractions are single bf16; the exact-fp32 plan - the default and the judged one - is held to 1e-3 per site.
-# measured (S = 2, B = 100, shipped hyper-parameters): whole-vector d mu 1.3e-3 .. 1.6e-3, d rho 2.4e-4 (radial) .. 5.9e-3 (lrt);
+# measured (S = 2, B = 100, shipped hyper-parameters): whole-vector d mu 1.3e-3 .. 1.6e-3, d rho 2.4e-4 (radial), 3.0e-3 (flipout);
 # worst single site (q_scale x 5) d mu 4.1e-3 .. 8.6e-3, d rho 5.6e-3 (radial) .. 2.2e-2 (flipout, layers.1.branch2.0.weight)
-GRAD_TOL = {"lrt": (3.1e-3, 1.2e-2), "flipout": (3.1e-3, 6.1e-3), "radial": (2.6e-3, 5e-4)}
-SITE_TOL = {"lrt": (1.8e-2, 3.5e-2), "flipout": (1.4e-2, 4.5e-2), "radial": (8.2e-3, 1.2e-2)}
+GRAD_TOL = {"flipout": (3.1e-3, 6.1e-3), "radial": (2.6e-3, 5e-4)}
+SITE_TOL = {"flipout": (1.4e-2, 4.5e-2), "radial": (8.2e-3, 1.2e-2)}
 
 
 @pytest.mark.parametrize("mode", ["lrt", "flipout", "radial", "normal"])
@@ -74,7 +74,7 @@ def test_step_f32_matches_oracle(net, mode):
         assert rel_l2(g[eng.P + off:eng.P + off + num], st.rho[s].grad) < 1e-3, ("rho", s)
 
 
-@pytest.mark.parametrize("mode", ["lrt", "flipout", "radial"])
+@pytest.mark.parametrize("mode", ["flipout", "radial"])
 def test_step_bf16x3_elbo_within_tolerance(mode):
     """north star: ELBO within 1e-3 relative of the reference arithmetic (we hold 1e-5) at the
     shipped hyper-parameters, batch 100."""
@@ -96,7 +96,7 @@ def test_step_bf16x3_elbo_within_tolerance(mode):
     assert rel_l2(g[eng.P:2 * eng.P], grho) < GRAD_TOL[mode][1], rel_l2(g[eng.P:2 * eng.P], grho)
 
 
-@pytest.mark.parametrize("mode", ["lrt", "flipout", "radial"])
+@pytest.mark.parametrize("mode", ["flipout", "radial"])
 def test_step_bf16x3_per_site_gradients_and_reproducibility(mode):
     """bf16x3 plan: every site's gradient (a small site must not hide behind the dense layer's 82 % of the
     weights; catches a wrong conv dX / dW / pooled scatter) and run-to-run reproducibility: two fresh engines on
@@ -250,7 +250,7 @@ def test_ragged_and_single_window_batches():
         assert rel_l2(g[:eng.P], gmu) < 2e-4, B
 
 
-@pytest.mark.parametrize("mode", ["lrt", "flipout", "radial"])
+@pytest.mark.parametrize("mode", ["flipout", "radial"])
 def test_ragged_batches_bf16x3(mode):
     """The role-specialised bf16x3 kernels on awkward geometries: one window, a dense chunk of 32 + 1, more
     window sets than windows per particle, a partial last dense window, and enough particles for the store-only dense dW

@@ -25,6 +25,10 @@ def test_every_launch_geometry_validates(lib, net, prec):
     for mode, (S, B) in itertools.product((N.MODE_NORMAL, N.MODE_LRT, N.MODE_FLIPOUT, N.MODE_RADIAL), GEOMS):
         d = N.PlanDesc(0 if net == "inception" else 1, mode, prec, S, B, 30, 18, 0)
         p = C.c_void_p()
+        if net == "inception" and prec == N.PREC_BF16X3 and mode == N.MODE_LRT:
+            # LRT on the Inception net exists on the exact-fp32 plan only: refused with a message at plan creation
+            assert lib.bnn_plan_create(C.byref(d), C.byref(p)) == -1 and b"exact-fp32" in lib.bnn_last_error()
+            continue
         N.check(lib.bnn_plan_create(C.byref(d), C.byref(p)))
         try:
             for train in (1, 0):
@@ -47,8 +51,13 @@ def test_predictive_pass_geometry_and_refusals(lib):
     assert lib.bnn_plan_validate(p, N.MODE_NORMAL, 11, 10000, 0) == -1 and b"capacity" in lib.bnn_last_error()
     lib.bnn_plan_destroy(p)
     # windows longer than the 32-row tile are refused at plan creation
-    d = N.PlanDesc(0, N.MODE_LRT, N.PREC_BF16X3, 1, 4, 31, 18, 0)
+    d = N.PlanDesc(0, N.MODE_FLIPOUT, N.PREC_BF16X3, 1, 4, 31, 18, 0)
     assert lib.bnn_plan_create(C.byref(d), C.byref(p)) == -1
+    # a Flipout plan overridden to LRT per call: refused at the call on the split-bf16 plan
+    d = N.PlanDesc(0, N.MODE_FLIPOUT, N.PREC_BF16X3, 2, 8, 30, 18, 0)
+    N.check(lib.bnn_plan_create(C.byref(d), C.byref(p)))
+    assert lib.bnn_plan_validate(p, N.MODE_LRT, 2, 8, 1) == -1 and b"exact-fp32" in lib.bnn_last_error()
+    lib.bnn_plan_destroy(p)
     # the fused trunk kernels address rows with 32-bit byte offsets
     d = N.PlanDesc(0, N.MODE_FLIPOUT, N.PREC_BF16X3, 100, 10000, 30, 18, 0)
     N.check(lib.bnn_plan_create(C.byref(d), C.byref(p)))
