@@ -182,24 +182,30 @@ struct TfJobRun {
     const char* lr = in + i16 * RS;
     const char* lb = lr + g4 * 16;
     const uint32_t* sg = (const uint32_t*)(smem + TF_O_SGN) + (k & 3) * 80 + LY * 8;
-    const uint4* lut = (const uint4*)(smem + TF_O_LUT);
     constexpr int chb0 = NT * 16;
     // one accumulator per m-tile: out = bias + W_mu x  (+ Flipout: (s_out o dW o s_in) x, both signs folded into the dW fragment)
     f32x4 acc[2] = {bias, bias};
     f32x4 accv[2] = {biasv, biasv};   // LRT: var = sigma_b^2 + sigma_W^2 . x^2
-    // the window's sign words of this layer, once per job: the per-k-block table index is register arithmetic, the table
-    // read one LDS access (no chain of dependent LDS reads in front of a k-block's MFMAs)
-    uint32_t sw[4] = {0u, 0u, 0u, 0u}, so = 0;
+    // the window's sign words of this layer, once per job, with s_out of this lane's fragment row (cout) folded in and
+    // pre-shifted per lane: the sign of element j of k-block cb is bit 28 + j of sl0 / sl16 [word] (the block starts at bit 0
+    // or 16 of its word), so a fold is one constant shift + one bit operation (w ^ (shifted & 0x80000000)) per element.
+    // (A 32-entry LDS table of masks cost a dependent address chain + an LDS read per k-block in front of its MFMAs: one
+    // wave then issued an MFMA every 39.5 cycles instead of every 34.7 - tests/probes/mfma_mix.hip.)
+    uint32_t sl0[4] = {0u, 0u, 0u, 0u}, sl16[4] = {0u, 0u, 0u, 0u}, stl = 0;
     if constexpr (FO) {
+      const uint32_t so = 0u - ((sg[4 + (chb0 >> 5)] >> ((chb0 & 31) + i16)) & 1u);   // all ones: s_out = -1
 #pragma unroll
-      for (int w = 0; w < tf_cimg(LY) / 32; ++w) sw[w] = sg[w];
-      so = ((sg[4 + (chb0 >> 5)] >> ((chb0 & 31) + i16)) & 1u) << 4;   // s_out of this lane's fragment row (cout)
+      for (int w = 0; w < tf_cimg(LY) / 32; ++w) {
+        const uint32_t x = sg[w] ^ so;
+        sl0[w] = x << (28 - 4 * g4);
+        sl16[w] = x << (12 - 4 * g4);
+        if (w == 0) stl = x << (15 - g4);   // the tail channel 16 + g4 of a 20-channel input
+      }
     }
     // hipcc sinks every LDS read next to its first use (read, wait, 4 MFMAs, read, wait, ...): the operands of k-block
     // kb + 1 are fetched explicitly BEFORE the MFMAs of k-block kb, scheduling barriers keep the two groups apart
     struct Op {
       f32x4 x[2];
-      uint4 m;
       float xt[2];
       f32x4 wbk;
     };
@@ -208,11 +214,6 @@ struct TfJobRun {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) o.x[mt] = *(const f32x4*)(lb + (mt * 16 + tap - PAD + HALO) * RS + (tf_inch(LY) + cb * 16) * 4);
       if constexpr (WBL) o.wbk = *(const f32x4*)(smem + TF_O_WB + kb * 1024 + lane * 16);
-      if constexpr (FO) {
-        // s_in of the layer's own input channels cb*16 + 4 g4 .. + 3
-        const uint32_t nib = (sw[(cb * 16) >> 5] >> (((cb * 16) & 31) + 4 * g4)) & 15u;
-        o.m = lut[so | nib];
-      }
       if constexpr (TAIL) {
         if (cb == CB - 1) {
 #pragma unroll
@@ -237,11 +238,19 @@ struct TfJobRun {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wa[kb][j], cur.x[mt][j], acc[mt]);
       if constexpr (FO) {
-        const f32x4 wbm = xor4(wb[kb], cur.m);
+        // s_in of the layer's own input channels cb*16 + 4 g4 + j (and s_out of the row) into the dW fragment
+        const uint32_t sgw = ((cb * 16) & 31) ? sl16[(cb * 16) >> 5] : sl0[(cb * 16) >> 5];
+        f32x4 wbm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wbm[j] = xor1(wb[kb][j], (sgw << (3 - j)) & 0x80000000u);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(wbm[j], cur.x[mt][j], acc[mt]);
+        // the folds first, each into its own register, in the shadow of the previous k-block's last MFMAs (hipcc otherwise
+        // sinks every fold next to its use)
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
       }
       if constexpr (LRT) {
         f32x4 x2[2];
@@ -261,8 +270,7 @@ struct TfJobRun {
             for (int mt = 0; mt < 2; ++mt) accv[mt] = mfma4(tb[tap], cur.xt[mt] * cur.xt[mt], accv[mt]);
           }
           if constexpr (FO) {
-            const uint32_t m = (((sw[0] >> (16 + g4)) & 1u) ^ (so >> 4)) << 31;
-            const float tbm = xor1(tb[tap], m);
+            const float tbm = xor1(tb[tap], stl & 0x80000000u);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma4(tbm, cur.xt[mt], acc[mt]);
           }
@@ -347,13 +355,13 @@ struct TfJobRun {
           *(f32x4*)(img + (row + HALO) * TF_RSB + (OOFF + chb) * 4) = v[mt];
           if constexpr (TRAIN && !(TFV & 32)) {
             char* g = (char*)(OUTK == 0 ? A.act1 : A.mid);
-            *(f32x4*)(g + ((R0 + (unsigned)row) * 512u + (unsigned)((OOFF + chb) * 4))) = v[mt];
+            if constexpr (!(TFV & 256)) *(f32x4*)(g + ((R0 + (unsigned)row) * 512u + (unsigned)((OOFF + chb) * 4))) = v[mt];
             const uint32_t bits = (v[mt][0] > 0.f ? 1u : 0u) | (v[mt][1] > 0.f ? 2u : 0u) | (v[mt][2] > 0.f ? 4u : 0u) | (v[mt][3] > 0.f ? 8u : 0u);
-            (OUTK == 0 ? A.m_act1 : A.m_mid)[(R0 + (unsigned)row) * 32u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)bits;
+            if constexpr (!(TFV & 128)) (OUTK == 0 ? A.m_act1 : A.m_mid)[(R0 + (unsigned)row) * 32u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)bits;
           }
         } else {
-          if constexpr (!(TFV & 32)) *(f32x4*)((char*)A.act2 + ((R0 + (unsigned)row) * 320u + (unsigned)((OOFF + chb) * 4))) = v[mt];
-          if constexpr (TRAIN && !(TFV & 32)) {
+          if constexpr (!(TFV & (32 | 256))) *(f32x4*)((char*)A.act2 + ((R0 + (unsigned)row) * 320u + (unsigned)((OOFF + chb) * 4))) = v[mt];
+          if constexpr (TRAIN && !(TFV & (32 | 128))) {
             const uint32_t bits = (v[mt][0] > 0.f ? 1u : 0u) | (v[mt][1] > 0.f ? 2u : 0u) | (v[mt][2] > 0.f ? 4u : 0u) | (v[mt][3] > 0.f ? 8u : 0u);
             A.m_act2[(R0 + (unsigned)row) * 20u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)bits;
           }
@@ -396,7 +404,7 @@ struct TfJobRun {
         if (row < L) {
           char* img = smem + TF_A1B + par * 2 * TF_PA + TF_PA;
           *(f32x4*)(img + (row + HALO) * TF_RSB + (OOFF + chb) * 4) = p[mt];
-          if constexpr (TRAIN && !(TFV & 32)) A.amax[(R0 + (unsigned)row) * 32u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)code[mt];
+          if constexpr (TRAIN && !(TFV & (32 | 128))) A.amax[(R0 + (unsigned)row) * 32u + (unsigned)((OOFF + chb) >> 2)] = (unsigned char)code[mt];
         }
       }
     }
@@ -540,7 +548,6 @@ __global__ __launch_bounds__(TF_THREADS) void tf_fwd_kernel(const TfArgs A) {
   {
     uint32_t* z = (uint32_t*)smem;
     for (int k = tid; k < TF_O_LUT / 4; k += TF_THREADS) z[k] = 0u;
-    build_sign_lut_f32((uint4*)(smem + TF_O_LUT), tid);
   }
 #define TF_ROLE(LD, ...) tf_role<EM, TRAIN, DROP, LD, __VA_ARGS__>(A, smem, s, split, nwin, lane)
 #define TJ(...) TJob<__VA_ARGS__>
