@@ -1771,16 +1771,22 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = wave & 3, mh = wave >> 2;
-  int bid = blockIdx.x;
-  const int rs = bid % A.nrs;
-  bid /= A.nrs;
-  const int chunk = bid % A.nchunk, s = bid / A.nchunk;
-  if (s >= A.S) return;
-  const int b0 = rs * A.rows_per_wg, b1 = min(A.B, b0 + A.rows_per_wg);
-  const int nsteps = (b1 - b0 + FDF_ROWS - 1) / FDF_ROWS;
+  build_sign_lut_f32((uint4*)(smem + FDF_O_LUT), tid);
+  // Work items = (particle, chunk, 32-row step), numbered pair-major; workgroup g takes the contiguous items
+  // [items g / G, items (g + 1) / G): every CU gets the same number of row steps whatever S * nchunk is (100 pairs x 2 row
+  // ranges used to leave 56 of 256 CUs idle).  A range that crosses a pair boundary reloads the weight fragments once.
+  const int SP = (A.B + FDF_ROWS - 1) / FDF_ROWS;
+  const long items = (long)A.S * A.nchunk * SP;
+  long item = items * blockIdx.x / gridDim.x;
+  const long item_end = items * (blockIdx.x + 1) / gridDim.x;
+  while (item < item_end) {
+  const int pair = (int)(item / SP), t_first = (int)(item - (long)pair * SP);
+  const int nsteps = (int)min((long)(SP - t_first), item_end - item);
+  item += nsteps;
+  const int s = pair / A.nchunk, chunk = pair - s * A.nchunk;
+  const int b0 = t_first * FDF_ROWS, b1 = min(A.B, b0 + nsteps * FDF_ROWS);
   const int ch0 = chunk * FDF_CH;
   const int w0 = ch0 >> 5;   // first s_in word of the chunk
-  build_sign_lut_f32((uint4*)(smem + FDF_O_LUT), tid);
   // ---- weight fragments: rows nt*16 + i16 of the forward image, k-blocks of the chunk ----
   f32x4 wa[FDF_KB], wb[TWO ? FDF_KB : 1];
   {
@@ -1897,6 +1903,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
     }
     lds_barrier();
   }
+  }   // next (pair, step range) of this workgroup
 }
 
 // ==========================================================================================
@@ -1983,15 +1990,19 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c0t = wave & 3, mh = wave >> 2;   // c-tiles c0t, c0t + 4, c0t + 8, c0t + 12 (< 15); row half
-  int bid = blockIdx.x;
-  const int rs = bid % A.nrs;
-  bid /= A.nrs;
-  const int chunk = bid % A.nchunk, s = bid / A.nchunk;
-  if (s >= A.S) return;
-  const int b0 = rs * A.rows_per_wg, b1 = min(A.B, b0 + A.rows_per_wg);
-  const int nsteps = (b1 - b0 + FDF_ROWS - 1) / FDF_ROWS;
-  const int ch0 = chunk * FDF_CH, w0 = ch0 >> 5;
   build_sign_lut_f32((uint4*)(smem + FDX_O_LUT), tid);
+  // balanced (particle, chunk, row step) item ranges: see densef_fwd_kernel
+  const int SP = (A.B + FDF_ROWS - 1) / FDF_ROWS;
+  const long items = (long)A.S * A.nchunk * SP;
+  long item = items * blockIdx.x / gridDim.x;
+  const long item_end = items * (blockIdx.x + 1) / gridDim.x;
+  while (item < item_end) {
+  const int pair = (int)(item / SP), t_first = (int)(item - (long)pair * SP);
+  const int nsteps = (int)min((long)(SP - t_first), item_end - item);
+  item += nsteps;
+  const int s = pair / A.nchunk, chunk = pair - s * A.nchunk;
+  const int b0 = t_first * FDF_ROWS, b1 = min(A.B, b0 + nsteps * FDF_ROWS);
+  const int ch0 = chunk * FDF_CH, w0 = ch0 >> 5;
   f32x4 wa[4][4], wb[TWO ? 4 : 1][4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
@@ -2098,6 +2109,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
     }
     lds_barrier();
   }
+  }   // next (pair, step range) of this workgroup
 }
 
 template <int EM>

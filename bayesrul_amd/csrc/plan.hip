@@ -1799,6 +1799,12 @@ static void densef_geometry(const GroupArgs& A, int nchunk, int max_rs, int* nrs
   *rows_per_wg = ((steps + r - 1) / r) * FDF_ROWS;
 }
 
+// forward / dX of the wide dense layer: one workgroup per CU, each a contiguous range of (particle, chunk, 32-row step) items
+static unsigned densef_balanced_grid(const GroupArgs& A, int nchunk) {
+  const long items = (long)A.cg.S * nchunk * ((A.cg.B + FDF_ROWS - 1) / FDF_ROWS);
+  return (unsigned)std::max(1L, std::min(items, 256L));
+}
+
 static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last, const BnnDropout* drop, bool train) {
   if (em == EM_LRT && !fuse_last) return fail(BNN_E_INVALID, "fp32 LRT dense forward needs the fused hidden / last layer launch");
   if (drop && !fuse_last) return fail(BNN_E_INVALID, "MC-dropout needs the fused hidden / last layer launch");
@@ -1822,9 +1828,8 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   F.S = A.cg.S;
   F.B = A.cg.B;
   F.nchunk = ly.cin / FDF_CH;
-  densef_geometry(A, F.nchunk, 1 << 20, &F.nrs, &F.rows_per_wg);
   static_assert(FDF_LDS <= 160 * 1024 && FDX_LDS <= 160 * 1024 && DWF_LDS <= 160 * 1024, "LDS budgets");
-  const unsigned grid = (unsigned)(F.S * F.nchunk * F.nrs);
+  const unsigned grid = densef_balanced_grid(A, F.nchunk);
   ProfScope ps_(pf, PK_FWD, gi, st);
   ps_.name("densef_fwd_kernel<%d>", em);
   BNN_DRY_RETURN();
@@ -1977,8 +1982,7 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
     }
   }
   {
-    densef_geometry(A, F.nchunk, 1 << 20, &F.nrs, &F.rows_per_wg);
-    const unsigned grid = (unsigned)(F.S * F.nchunk * F.nrs);
+    const unsigned grid = densef_balanced_grid(A, F.nchunk);
     ProfScope ps_(pf, PK_DX, gi, st);
     ps_.name("densef_dx_kernel<%d>", em);
     if (!g_dry) {
