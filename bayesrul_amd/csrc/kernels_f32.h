@@ -26,6 +26,15 @@
 #include "kernels_dense_ks.h"   // HL_ROWS, DenseKsFinArgs
 
 enum { TF_WAVES = 8, TF_THREADS = TF_WAVES * 64 };
+
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): the workgroups with equal blockIdx % 8 share an
+// XCD.  This bijection hands each of those groups a CONTIGUOUS range of logical ids, so that the workgroups of one
+// particle (the same weight fragments: 0.3 MB per workgroup of the trunk forward) fill ONE L2 instead of all eight.
+// Speed only - nothing depends on the placement.
+__device__ __forceinline__ unsigned xcd_contiguous_id(unsigned bid, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
 enum {
   TF_XC = 20,                          // channels of an x image row: 18 features + 2 zero pads (5 k-steps instead of 8)
   TF_RSX = TF_XC * 4 + 16,             // 96 bytes: pitch 6
@@ -543,7 +552,8 @@ __global__ __launch_bounds__(TF_THREADS) void tf_fwd_kernel(const TfArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = blockIdx.x / A.nsplit, split = blockIdx.x - s * A.nsplit;
+  const int wg = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int s = wg / A.nsplit, split = wg - s * A.nsplit;
   const int nwin = (A.B - split + A.nsplit - 1) / A.nsplit;
   {
     uint32_t* z = (uint32_t*)smem;
@@ -980,7 +990,8 @@ __global__ __launch_bounds__(TF_THREADS) void tf_dx_kernel(const TfDxArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = blockIdx.x / A.nsplit, split = blockIdx.x - s * A.nsplit;
+  const int wg = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int s = wg / A.nsplit, split = wg - s * A.nsplit;
   const int nwin = (A.B - split + A.nsplit - 1) / A.nsplit;
   {
     uint32_t* z = (uint32_t*)smem;
@@ -1279,7 +1290,8 @@ __global__ __launch_bounds__(TF_THREADS) void tf_dx_lrt_kernel(const TfDxArgs A)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s = blockIdx.x / A.nsplit, split = blockIdx.x - s * A.nsplit;
+  const int wg = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  const int s = wg / A.nsplit, split = wg - s * A.nsplit;
   const int nwin = (A.B - split + A.nsplit - 1) / A.nsplit;
   {
     uint32_t* z = (uint32_t*)smem;
@@ -1777,8 +1789,9 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
   // ranges used to leave 56 of 256 CUs idle).  A range that crosses a pair boundary reloads the weight fragments once.
   const int SP = (A.B + FDF_ROWS - 1) / FDF_ROWS;
   const long items = (long)A.S * A.nchunk * SP;
-  long item = items * blockIdx.x / gridDim.x;
-  const long item_end = items * (blockIdx.x + 1) / gridDim.x;
+  const long wg = xcd_contiguous_id(blockIdx.x, gridDim.x);   // neighbours in item space (the same weight fragments) share an L2
+  long item = items * wg / gridDim.x;
+  const long item_end = items * (wg + 1) / gridDim.x;
   while (item < item_end) {
   const int pair = (int)(item / SP), t_first = (int)(item - (long)pair * SP);
   const int nsteps = (int)min((long)(SP - t_first), item_end - item);
@@ -1794,6 +1807,11 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
     const float* pb = A.wb + A.stride_b * s + (long)(nt * 16 + i16) * A.KP + ch0 + 4 * g4;
 #pragma unroll
     for (int kb = 0; kb < FDF_KB; ++kb) {
+      if constexpr (TFV & 512) {   // diagnostics: no weight loads
+        wa[kb] = f32x4{1.f, 2.f, 3.f, (float)lane};
+        if constexpr (TWO) wb[kb] = f32x4{1.f, 2.f, 3.f, (float)lane};
+        continue;
+      }
       wa[kb] = *(const f32x4*)(pa + kb * 16);
       if constexpr (TWO) wb[kb] = *(const f32x4*)(pb + kb * 16);
     }
@@ -1926,7 +1944,7 @@ struct DfBwdArgs {
   const unsigned char* m_x;             // [S*B][x_ctot / 4] nibble masks [X > 0] of the layer's input (null: dX is stored unmasked)
   float x_scale, h_scale;               // MC-dropout: 1 / (1 - p/4) on dX, 1 / (1 - p) on dz = dH [H > 0]; else 1
   float* gw_a; float* gw_b; float* gb_a;   // per-particle gradient images of the layer (forward layout [64][KP]) / bias gradients
-  float* gw2_a; float* gw2_b; float* gb2_a;   // the second row range's partial images (same strides; summed by dense_add2_kernel)
+  float* gw2_a; float* gw2_b; float* gb2_a;   // partial images of row ranges 1 .. nrs - 1: image (rs - 1) * S + s, same strides (summed by dense_addn_kernel)
   const float* qh;                      // LRT: q = eps / (2 sd) of the layer's output [S*B][64]: dVar = dz q
   float* gb_b; float* gb2_b;            // LRT: gradient of sigma_b^2 (+ its second-range partial)
   long gw_stride; int gb_stride;
@@ -1994,8 +2012,9 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
   // balanced (particle, chunk, row step) item ranges: see densef_fwd_kernel
   const int SP = (A.B + FDF_ROWS - 1) / FDF_ROWS;
   const long items = (long)A.S * A.nchunk * SP;
-  long item = items * blockIdx.x / gridDim.x;
-  const long item_end = items * (blockIdx.x + 1) / gridDim.x;
+  const long wg = xcd_contiguous_id(blockIdx.x, gridDim.x);   // neighbours in item space (the same weight fragments) share an L2
+  long item = items * wg / gridDim.x;
+  const long item_end = items * (wg + 1) / gridDim.x;
   while (item < item_end) {
   const int pair = (int)(item / SP), t_first = (int)(item - (long)pair * SP);
   const int nsteps = (int)min((long)(SP - t_first), item_end - item);
@@ -2243,11 +2262,12 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
     lds_barrier();
   }
   // ---- flush: transposed tiles (rows = input channels, columns = couts), plain stores.  Row range 0 writes the particle's
-  // gradient image, range 1 (if any) a second image that dense_add2_kernel adds afterwards: float atomics from 200
-  // workgroups onto the same 12 MB cost more than the kernel's MFMAs ----
+  // gradient image, ranges 1 .. nrs - 1 partial images that dense_addn_kernel adds afterwards in a fixed order: float
+  // atomics from 200 workgroups onto the same 12 MB cost more than the kernel's MFMAs ----
   const int n = nt * 16 + i16;
-  float* gwa = (rs == 0 ? A.gw_a : A.gw2_a) + A.gw_stride * s + (long)n * A.KP + ch0 + 4 * g4;
-  float* gwb = (rs == 0 ? A.gw_b : A.gw2_b) + A.gw_stride * s + (long)n * A.KP + ch0 + 4 * g4;
+  const long pimg = rs == 0 ? s : (long)(rs - 1) * A.S + s;
+  float* gwa = (rs == 0 ? A.gw_a : A.gw2_a) + A.gw_stride * pimg + (long)n * A.KP + ch0 + 4 * g4;
+  float* gwb = (rs == 0 ? A.gw_b : A.gw2_b) + A.gw_stride * pimg + (long)n * A.KP + ch0 + 4 * g4;
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const int ct = cpar + 2 * m;
@@ -2260,26 +2280,37 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
     float t = bsum;
     t += __shfl_xor(t, 16, 64);
     t += __shfl_xor(t, 32, 64);
-    if (g4 == 0) (rs == 0 ? A.gb_a : A.gb2_a)[(long)A.gb_stride * s + n] = t;
+    if (g4 == 0) (rs == 0 ? A.gb_a : A.gb2_a)[(long)A.gb_stride * pimg + n] = t;
     if constexpr (LRT) {
       float tv = bsumv;
       tv += __shfl_xor(tv, 16, 64);
       tv += __shfl_xor(tv, 32, 64);
-      if (g4 == 0) (rs == 0 ? A.gb_b : A.gb2_b)[(long)A.gb_stride * s + n] = tv;
+      if (g4 == 0) (rs == 0 ? A.gb_b : A.gb2_b)[(long)A.gb_stride * pimg + n] = tv;
     }
   }
 }
 
-// dst[s][0 .. n) += src[s][0 .. n) over S particles (strides in floats); 4 floats per thread
-__global__ void dense_add2_kernel(float* dst, const float* src, long n, long stride, int S) {
+// dst[s][0 .. n) += sum over k < np of src[k * S + s][0 .. n), in that order (strides in floats), for up to four buffers in
+// one launch (blockIdx.z: weight images of slots A and B, bias sums); 4 floats per thread
+struct DenseAddJobs {
+  float* dst[4];
+  const float* src[4];
+  long n[4], stride[4];
+  int S, np;
+};
+__global__ void dense_addn_kernel(const DenseAddJobs J) {
+  const int job = blockIdx.z;
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int s = blockIdx.y;
-  if (i >= n || s >= S) return;
-  f32x4* d = (f32x4*)(dst + stride * s + i);
-  const f32x4 a = *(const f32x4*)(src + stride * s + i);
+  if (i >= J.n[job] || s >= J.S) return;
+  const long stride = J.stride[job];
+  f32x4* d = (f32x4*)(J.dst[job] + stride * s + i);
   f32x4 v = *d;
+  for (int k = 0; k < J.np; ++k) {
+    const f32x4 a = *(const f32x4*)(J.src[job] + stride * ((long)k * J.S + s) + i);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] += a[r];
+    for (int r = 0; r < 4; ++r) v[r] += a[r];
+  }
   *d = v;
 }
 

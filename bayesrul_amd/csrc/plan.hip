@@ -112,6 +112,7 @@ struct ProfScope {
     if (e) (void)hipEventRecord(e[1], st);
   }
 };
+enum { DENSEF_DW_PARTS = 25 };   // partial images of densef_dw_kernel: (row ranges - 1) x particles <= 256 / 10 chunks
 enum { PK_FWD = 0, PK_DX = 1, PK_DW = 2, PK_SAMPLE = 3, PK_HEAD = 4, PK_FINALIZE = 5, PK_ADAM = 6, PK_POOLBWD = 7, PK_NOISE = 8 };
 
 
@@ -135,7 +136,7 @@ struct BnnPlan {
   size_t ws_bytes = 0;
   size_t o_slab_a[3], o_slab_b[3], o_slab_ba[3];   // partial images of the fused trunk dW kernels
   size_t o_slab_bb = 0;                            // fp32 LRT: partial sums of the sigma_b^2 gradients
-  size_t o_dw2_a = 0, o_dw2_b = 0, o_dw2_ba = 0, o_dw2_bb = 0;   // fp32 plan: second partial images of the wide dense layer's dW
+  size_t o_dw2_a = 0, o_dw2_b = 0, o_dw2_ba = 0, o_dw2_bb = 0;   // fp32 plan: partial images of the wide dense layer's dW (DENSEF_DW_PARTS x (row range, particle))
   size_t o_dksv = 0;                               // fp32 LRT plan: partial variances of the K-split dense forward
   size_t o_mact2 = 0;                              // fp32 plan: nibble masks [ACT2 > 0] ([rows][20 B])
   size_t o_mact1 = 0, o_mmid = 0;                  // bit masks [ACT1 > 0] / [MID > 0] of the trunk kernels: [rows][16 B]
@@ -435,12 +436,12 @@ static void layout_workspace(BnnPlan* p) {
     p->o_mlp_dz4 = take((size_t)cap * 8 * 2 * 2);
   }
   if (p->d.prec == BNN_PREC_F32 && p->d.net == BNN_NET_INCEPTION && p->layers[10].cin % FDF_CH == 0) {
-    // second-row-range partial images of densef_dw_kernel: the dense layer's part of slot A | slot B, and its biases
+    // partial images of densef_dw_kernel's row ranges 1, 2, ...: the dense layer's part of slot A | slot B, and its biases
     // (laid out like the gradient images themselves: same offsets and particle strides)
-    p->o_dw2_a = take((size_t)S * p->img_total * 4);
-    p->o_dw2_b = take((size_t)S * p->img_total * 4);
-    p->o_dw2_ba = take((size_t)S * p->bias_total * 4);
-    p->o_dw2_bb = take((size_t)S * p->bias_total * 4);
+    p->o_dw2_a = take((size_t)DENSEF_DW_PARTS * p->img_total * 4);
+    p->o_dw2_b = take((size_t)DENSEF_DW_PARTS * p->img_total * 4);
+    p->o_dw2_ba = take((size_t)DENSEF_DW_PARTS * p->bias_total * 4);
+    p->o_dw2_bb = take((size_t)DENSEF_DW_PARTS * p->bias_total * 4);
     p->dks_rows = cap;
     p->o_dks = take((size_t)(p->layers[10].cin / FDF_CH) * cap * 64 * 4);   // partial pre-activations of densef_fwd_kernel
     p->o_dksv = p->d.mode == BNN_MODE_LRT ? take((size_t)(p->layers[10].cin / FDF_CH) * cap * 64 * 4) : 0;   // LRT: partial variances
@@ -1950,8 +1951,10 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   F.nchunk = ly.cin / FDF_CH;
   if (br.dx_t < 0 || A.t[br.dx_t].ctot != F.x_ctot) return fail(BNN_E_INVALID, "fp32 dense backward: gradient tensor shape");
   {
-    // dW: at most two row ranges per (particle, chunk) - two float atomics per element onto the zeroed images commute
-    densef_geometry(A, F.nchunk, 2, &F.nrs, &F.rows_per_wg);
+    // dW: up to 8 row ranges per (particle, chunk), every range but the first into a partial image of its own; (nrs - 1) * S
+    // <= 25 partial images exist in the workspace (nrs <= 256 / (S * nchunk))
+    densef_geometry(A, F.nchunk, 8, &F.nrs, &F.rows_per_wg);
+    if ((long)(F.nrs - 1) * F.S > DENSEF_DW_PARTS) return fail(BNN_E_INVALID, "internal: dense dW partial images");
     const unsigned grid = (unsigned)(F.S * F.nchunk * F.nrs);
     ProfScope ps_(pf, PK_DW, gi, st);
     ps_.name("densef_dw_kernel<%d>", em);
@@ -1971,13 +1974,21 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
         BNN_TRY(set_lds(densef_dw_kernel<EM_FLIPOUT>, DWF_LDS));
         densef_dw_kernel<EM_FLIPOUT><<<dim3(grid), dim3(TF_THREADS), DWF_LDS, st>>>(F);
       }
-      if (F.nrs == 2) {
+      if (F.nrs > 1) {
         const long n = (long)ly.cout * ly.KP;
-        const dim3 ag((unsigned)((n / 4 + 255) / 256), (unsigned)F.S);
-        dense_add2_kernel<<<ag, dim3(256), 0, st>>>(F.gw_a, F.gw2_a, n, F.gw_stride, F.S);
-        if (em != EM_PLAIN) dense_add2_kernel<<<ag, dim3(256), 0, st>>>(F.gw_b, F.gw2_b, n, F.gw_stride, F.S);
-        dense_add2_kernel<<<dim3(1, (unsigned)F.S), dim3(256), 0, st>>>(F.gb_a, F.gb2_a, 64, F.gb_stride, F.S);
-        if (em == EM_LRT) dense_add2_kernel<<<dim3(1, (unsigned)F.S), dim3(256), 0, st>>>(F.gb_b, F.gb2_b, 64, F.gb_stride, F.S);
+        DenseAddJobs J{};
+        int nj = 0;
+        auto job = [&](float* dst, const float* src, long cnt, long stride) {
+          J.dst[nj] = dst; J.src[nj] = src; J.n[nj] = cnt; J.stride[nj] = stride;
+          ++nj;
+        };
+        job(F.gw_a, F.gw2_a, n, F.gw_stride);
+        if (em != EM_PLAIN) job(F.gw_b, F.gw2_b, n, F.gw_stride);
+        job(F.gb_a, F.gb2_a, 64, F.gb_stride);
+        if (em == EM_LRT) job(F.gb_b, F.gb2_b, 64, F.gb_stride);
+        J.S = F.S;
+        J.np = F.nrs - 1;
+        dense_addn_kernel<<<dim3((unsigned)((n / 4 + 255) / 256), (unsigned)F.S, (unsigned)nj), dim3(256), 0, st>>>(J);
       }
     }
   }
@@ -2124,7 +2135,7 @@ static int prepare_fused_tail(BnnPlan* p, const BnnElboArgs* a, Ctx* c) {
   }
   if (tfd) {
     // fp32 plan: every gradient element of the conv layers (slab reduction) and of the wide dense layer (densef_dw_kernel,
-    // dense_add2_kernel) is STORED; the last layer's few elements, which the head launch adds to, were zeroed by the fin
+    // dense_addn_kernel) is STORED; the last layer's few elements, which the head launch adds to, were zeroed by the fin
     // kernel of the forward: no fill
     c->grads_zeroed = true;
     return 0;
