@@ -1807,7 +1807,7 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
     const float* pb = A.wb + A.stride_b * s + (long)(nt * 16 + i16) * A.KP + ch0 + 4 * g4;
 #pragma unroll
     for (int kb = 0; kb < FDF_KB; ++kb) {
-      if constexpr (TFV & 512) {   // diagnostics: no weight loads
+      if ((TFV & 512) || ((TFV & 1024) && mh == 1)) {   // diagnostics: no weight loads (1024: by one row half's waves only)
         wa[kb] = f32x4{1.f, 2.f, 3.f, (float)lane};
         if constexpr (TWO) wb[kb] = f32x4{1.f, 2.f, 3.f, (float)lane};
         continue;
