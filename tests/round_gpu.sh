@@ -11,6 +11,7 @@ for wl in flipout_conv_s10 radial_conv_s20 predict_conv_s100; do
   timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-companions --workload $wl --prec bf16x3 2>/dev/null > gpurun_out/wl_${wl}_bf16x3.json
 done
 fi
+[ -n "$SKIP_PROF" ] && exit 0
 for job in ${1:-flipout_conv_s10:f32 flipout_conv_s10:bf16x3 radial_conv_s20:f32 predict_conv_s100:f32 lrt_conv_s1:f32 lrt_linear_s1:bf16x3}; do
   wl=${job%%:*}; prec=${job##*:}
   bash tests/prof_gpu.sh $wl $prec > gpurun_out/prof_${wl}_${prec}.log 2>&1
