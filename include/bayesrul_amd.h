@@ -41,8 +41,9 @@ enum {
 enum { BNN_NET_INCEPTION = 0, BNN_NET_LINEAR = 1 };
 /* estimator: bayesian.py:66-85 (fit_context lrt|flipout|null, guide normal|radial) */
 enum { BNN_MODE_NORMAL = 0, BNN_MODE_LRT = 1, BNN_MODE_FLIPOUT = 2, BNN_MODE_RADIAL = 3 };
-/* contraction arithmetic: exact f32 MFMA, or split-bf16 (hi+lo, 3 MFMAs on the mean path)
- * with fp32 accumulation */
+/* contraction arithmetic: exact f32 MFMA (the reference trains in fp32: conf/trainer/default.yaml:8-12), or split-bf16
+ * (hi+lo, 3 MFMAs on the mean path) with fp32 accumulation.  BNN_MODE_LRT on BNN_NET_INCEPTION is implemented on
+ * BNN_PREC_F32 only: bnn_plan_create (and a per-call mode override) returns BNN_E_INVALID for it on a BNN_PREC_BF16X3 plan */
 enum { BNN_PREC_F32 = 0, BNN_PREC_BF16X3 = 1 };
 
 typedef struct BnnPlan BnnPlan;
