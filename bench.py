@@ -16,6 +16,7 @@ Besides the contract's fields the line carries
   fast_plan     the same workload on the split-bf16 plan (`--prec bf16x3`: narrower than the reference's fp32, reported
                 beside the judged fp32 line, never as `value`)
   b100          the same workload at the reference's batch of 100 windows (launch-bound regime)
+  shipped_lrt_s1_b100   the reference's shipped LRT experiment at its own settings (1 MC sample, batch 100), exact fp32
   cpu_baseline  the CPU restatement (oracle/, kind "port") on this box's host cores: all cores at the workload's own
                 batch, one thread on a smaller sample
 """
@@ -351,6 +352,25 @@ def main():
                 companions["b100"] = {"timed_steps": 200, "windows_per_gpu": 100, "ms_per_step": m,
                                       "value": S * 100 / (m * 1e-3)}
                 del eng100
+                torch.cuda.empty_cache()
+            # the reference's shipped LRT experiment at its own settings (conf/experiment/ncmapss_lrt.yaml:17-28: LRT, 1 MC sample;
+            # conf/datamodule/ncmapss.yaml:3: batch 100): every kernel of the step is at its fixed cost there
+            if args.workload == "flipout_conv_s10":
+                w2 = WORKLOADS["lrt_conv_s1"]
+                e2 = SviEngine(net=w2["net"], guide=w2["guide"], fit_context=w2["fit_context"], prec="f32", max_particles=1, max_batch=100,
+                               device=dev)
+                e2.init_params(mu0_for(w2["net"]), w2["q_scale"])
+                x2, y2 = xg[:100].contiguous().to(dev), yg[:100].contiguous().to(dev)
+                h2 = AdamHyper(lr=w2["lr"], betas=(0.95, 0.999), clip_norm=15.0)
+
+                def step2():
+                    return e2.step(x2, y2, 1, N_DATA, 0.0, w2["prior_scale"], h2, seed=4321, keep=False)
+                for _ in range(5):
+                    step2()
+                m = median_ms(step2, 200)
+                companions["shipped_lrt_s1_b100"] = {"timed_steps": 200, "workload": "lrt_conv_s1", "mc_samples": 1, "windows_per_gpu": 100,
+                                                     "dtype": "f32", "ms_per_step": m, "value": 100 / (m * 1e-3)}
+                del e2
                 torch.cuda.empty_cache()
 
     if rank == 0:
