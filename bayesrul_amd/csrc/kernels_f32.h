@@ -756,7 +756,6 @@ struct TdJobB {
     const char* sl = smem + TD_O_DZ2 + (k % 3) * TD_P2;
     const uint32_t* sg = (const uint32_t*)(smem + TD_O_SGN) + (k % 3) * 80;
     const char* dzm = smem + TD_O_DZM + (k & 1) * TD_PM;
-    const uint4* lut = (const uint4*)(smem + TD_O_LUT);
     const int och = CT * 16 + 4 * g4, ci = CT * 16 + i16;
     const unsigned char* msl = (const unsigned char*)(smem + TD_O_MSK + (k % 3) * 3072);
     uint32_t mb[2], code[2];
@@ -770,20 +769,22 @@ struct TdJobB {
     f32x4 accp[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const char* b2 = sl + (i16 + HALO) * TD_RS2 + g4 * 16;
     const char* bm = dzm + (i16 + HALO) * TF_RSB + g4 * 16;
-    // sign words of the four layers once per job (registers): s_in bit of this lane's fragment row, s_out words
-    uint32_t sib[4] = {0u, 0u, 0u, 0u}, sow[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+    // sign words of the four layers once per job (registers): the s_out words (the contraction index here is the layer's
+    // cout) with s_in of this lane's fragment row (the layer's input channel) folded in; a fold is then a per-lane shift, a
+    // constant shift and one bit operation per element (tf_fwd_kernel's scheme: no LDS table read in front of a k-block)
+    uint32_t sox[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+    const int sh0 = 28 - 4 * g4, sh16 = 12 - 4 * g4;
     if constexpr (FO) {
       constexpr int lys[4] = {4, 5, 7, 9};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        sib[u] = ((sg[lys[u] * 8 + (ci >> 5)] >> (ci & 31)) & 1u) << 4;
-        sow[u][0] = sg[lys[u] * 8 + 4];
-        sow[u][1] = sg[lys[u] * 8 + 5];
+        const uint32_t si = 0u - ((sg[lys[u] * 8 + (ci >> 5)] >> (ci & 31)) & 1u);
+        sox[u][0] = sg[lys[u] * 8 + 4] ^ si;
+        sox[u][1] = sg[lys[u] * 8 + 5] ^ si;
       }
     }
     struct Op {
       f32x4 x[2];
-      uint4 m;
     };
     auto fetch = [&](int q, Op& o) __attribute__((always_inline)) {
 #pragma unroll
@@ -793,12 +794,6 @@ struct TdJobB {
         else if (q >= 9) bp = b2 + mt * 16 * TD_RS2 + (48 + (q - 9) * 16) * 4;
         else bp = bm + mt * 16 * TF_RSB + (q - 1) * 64;
         o.x[mt] = *(const f32x4*)bp;
-      }
-      if constexpr (FO) {
-        const int u = q == 0 ? 0 : (q < 5 ? 1 : (q < 9 ? 2 : 3));
-        const int bit = q_kb(q) * 16;
-        const uint32_t nib = (sow[u][bit >> 5] >> ((bit & 31) + 4 * g4)) & 15u;
-        o.m = lut[sib[u] | nib];
       }
     };
     Op cur, nxt;
@@ -815,7 +810,12 @@ struct TdJobB {
           ta = mfma4(wa[q][j], cur.x[mt][j], ta);
         }
       if constexpr (FO) {
-        const f32x4 wbm = xor4(wb[q], cur.m);
+        const int u = q == 0 ? 0 : (q < 5 ? 1 : (q < 9 ? 2 : 3));
+        const int bit = q_kb(q) * 16;
+        const uint32_t sgw = sox[u][bit >> 5] << ((bit & 31) ? sh16 : sh0);
+        f32x4 wbm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wbm[j] = xor1(wb[q][j], (sgw << (3 - j)) & 0x80000000u);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -823,6 +823,8 @@ struct TdJobB {
             f32x4& ta = q >= 9 ? accp[mt] : acc[mt];
             ta = mfma4(wbm[j], cur.x[mt][j], ta);
           }
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // the folds first (own registers), then the 16 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       cur = nxt;
@@ -1874,17 +1876,12 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
     }
     struct Op {
       f32x4 x;
-      uint4 m;
     };
-    auto fetchop = [&](int kb, Op& o) __attribute__((always_inline)) {
-      o.x = *(const f32x4*)(lb + kb * 64);
-      if constexpr (FO) {
-        // image channel of this lane's 4 values: c = ch0 + kb*16 + 4 g4; ch0 = 0 or 16 (mod 32)
-        // (the 16-channel block never straddles a sign word)
-        const uint32_t word = hi16 ? swr[(kb + 1) >> 1] : swr[kb >> 1];
-        o.m = lut[(word >> ((((kb + hi16) & 1) << 4) + 4 * g4)) & 15u];
-      }
-    };
+    auto fetchop = [&](int kb, Op& o) __attribute__((always_inline)) { o.x = *(const f32x4*)(lb + kb * 64); };
+    // s_in of this row into the activation fragment: image channel of the lane's 4 values c = ch0 + kb*16 + 4 g4, ch0 = 0 or 16
+    // (mod 32), so a 16-channel block starts at bit 0 or 16 of its sign word; the block's bits go to the top of a register with
+    // a per-lane shift, element j's bit to bit 31 with a constant one (tf_fwd_kernel's scheme: no LDS table read per k-block)
+    const int shE = hi16 ? 12 - 4 * g4 : 28 - 4 * g4, shO = hi16 ? 28 - 4 * g4 : 12 - 4 * g4;   // even / odd k-blocks
     Op cur, nxt;
     fetchop(0, cur);
 #pragma unroll
@@ -1892,7 +1889,12 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
       if (kb + 1 < FDF_KB) fetchop(kb + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
       f32x4 xs = cur.x;
-      if constexpr (FO) xs = xor4(cur.x, cur.m);
+      if constexpr (FO) {
+        const uint32_t word = hi16 ? swr[(kb + 1) >> 1] : swr[kb >> 1];
+        const uint32_t sgw = word << ((kb & 1) ? shO : shE);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xs[j] = xor1(cur.x[j], (sgw << (3 - j)) & 0x80000000u);
+      }
       if constexpr (LRT) xs = cur.x * cur.x;   // var = sigma^2 . x^2
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
