@@ -47,7 +47,7 @@ enum {
   TF_A1B = TF_O_A1 - HALO * TF_RSB,    // image row r + HALO is row r, as in the other images
   TF_O_MID = TF_O_A1 + 2 * 2 * TF_PA,  // [2 bufs][MID]
   TF_O_SGN = TF_O_MID + 2 * TF_PB,     // [4 slots][10 layers][8 words]
-  TF_O_LUT = TF_O_SGN + 4 * 80 * 4,    // 32 x 16 B: (s_out bit, 4 s_in bits) -> sign masks of a 4-channel fragment
+  TF_O_LUT = TF_O_SGN + 4 * 80 * 4,    // 32 x 16 B: sign-mask table of the first version (the folds are register arithmetic now; kept as a layout slot)
   TF_O_WB = TF_O_LUT + 32 * 16,        // LRT: sigma^2 fragments of the one job too wide for the register file: [20 k-blocks][64 lanes][16 B]
   TF_LDS = TF_O_WB + 20 * 1024
 };
@@ -621,7 +621,7 @@ enum {
   TD_O_DZ2 = 0,                        // [3 slots]
   TD_O_DZM = 3 * TD_P2,                // [2 bufs]
   TD_O_SGN = TD_O_DZM + 2 * TD_PM,     // [3 slots][80 words]
-  TD_O_LUT = TD_O_SGN + 3 * 80 * 4,
+  TD_O_LUT = TD_O_SGN + 3 * 80 * 4,    // (sign-mask table of the first version: unused, kept as a layout slot)
   TD_O_MSK = TD_O_LUT + 32 * 16,       // [3 slots][m_mid | m_act1 | amax][1024]: the window's mask / code bytes (L x 32 B each)
   TD_LDS = TD_O_MSK + 3 * 3 * 1024
 };
@@ -686,10 +686,12 @@ struct TdJobA {
     for (int mt = 0; mt < 2; ++mt) mb[mt] = msl[(mt * 16 + i16) * 32 + (och >> 2)];
     uint4 fm = make_uint4(0, 0, 0, 0);
     if constexpr (FO) {
-      const int ci = J * 16 + i16;   // input channel of the layer = row of the transposed fragment
-      const uint32_t si = (sg[ci >> 5] >> (ci & 31)) & 1u;
-      const uint32_t nib = (sg[4] >> (4 * g4)) & 15u;
-      fm = ((const uint4*)(smem + TD_O_LUT))[(si << 4) | nib];
+      // sign masks of the lane's 4 k elements (couts 4 g4 .. + 3 of the layer's 16) with s_in of its fragment row (the
+      // layer's input channel) folded in: register arithmetic, no LDS table
+      const int ci = J * 16 + i16;
+      const uint32_t si = 0u - ((sg[ci >> 5] >> (ci & 31)) & 1u);
+      const uint32_t w = (sg[4] ^ si) << (28 - 4 * g4);
+      fm = make_uint4((w << 3) & 0x80000000u, (w << 2) & 0x80000000u, (w << 1) & 0x80000000u, w & 0x80000000u);
     }
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const char* lb = sl + i16 * TD_RS2 + (CH0 + 4 * g4) * 4;
@@ -998,7 +1000,6 @@ __global__ __launch_bounds__(TF_THREADS) void tf_dx_kernel(const TfDxArgs A) {
   {
     uint32_t* z = (uint32_t*)smem;
     for (int k = tid; k < TD_O_LUT / 4; k += TF_THREADS) z[k] = 0u;
-    build_sign_lut_f32((uint4*)(smem + TD_O_LUT), tid);
   }
   switch (wave) {
     case 0: td_role<EM, PRE, 0>(A, smem, s, split, nwin, lane); break;
