@@ -250,6 +250,23 @@ def test_ragged_and_single_window_batches():
         assert rel_l2(g[:eng.P], gmu) < 2e-4, B
 
 
+@pytest.mark.parametrize("mode,S,B", [("lrt", 1, 300), ("flipout", 2, 257), ("radial", 3, 97), ("flipout", 8, 41)])
+def test_fp32_dense_scheduling_geometries(mode, S, B):
+    """The wide dense layer on the exact-fp32 plan: workgroups take balanced (particle, chunk, row step) item ranges that cross
+    pair boundaries (forward, dX), and the dW splits a pair's rows into up to 8 ranges whose partial images one launch adds in
+    order (S = 1, B = 300: 8 ranges; S = 2: 8 ranges x 2 particles; S = 3: 4 row steps; S = 8: 2 steps, 3 ranges).  Every site's
+    gradient against the f64 oracle, so a mis-addressed partial image or a row step counted twice cannot hide."""
+    eng, cfg, st, x, y, noise, (ps, qs, lr) = _setup("inception", mode, "f32", S, B, q_boost=20.0)
+    inj = to_injected(eng, cfg, noise, B)
+    res = eng.step(x.cuda(), y.cuda(), S, N_DATA, 0.0, ps, None, noise=inj)
+    loss_o, aux = st.loss_and_grads(x, y, noise)
+    assert abs(float(res[0]) - float(loss_o)) <= 2e-5 * abs(float(loss_o)), (float(res[0]), float(loss_o))
+    g = eng.grad.cpu()
+    for s, off, num in eng.sites:
+        assert rel_l2(g[off:off + num], st.mu[s].grad) < 1e-3, ("mu", s)
+        assert rel_l2(g[eng.P + off:eng.P + off + num], st.rho[s].grad) < 1e-3, ("rho", s)
+
+
 @pytest.mark.parametrize("mode", ["flipout", "radial"])
 def test_ragged_batches_bf16x3(mode):
     """The role-specialised bf16x3 kernels on awkward geometries: one window, a dense chunk of 32 + 1, more
