@@ -1765,6 +1765,47 @@ enum {
   FDF_LDS = FDF_O_LUT + 32 * 16
 };
 
+// Work items of the dense forward / dX = (particle, chunk, 32-row step), numbered pair-major (pair = particle * nchunk + chunk,
+// SP steps each).  Two ways to deal them to the workgroups (the host takes the cheaper one, densef_schedule in plan.hip):
+//   q == 0 : workgroup g takes the contiguous items [items g / G, items (g + 1) / G): equal step counts whatever S * nchunk
+//            is; a range that crosses a pair boundary reloads the weight fragments (a second ~7 us load for most workgroups)
+//   q > 0  : every pair is cut into k = SP / q full ranges of q steps (one workgroup, one fragment load each); the remainders
+//            (r = SP - k q steps per pair) are packed m = q / r to a workgroup.  S = 10, B = 1000: 200 workgroups with 13
+//            steps and one load, 50 with 2 x 6 steps.
+struct DfSeg {
+  int pair, t0, n;
+};
+__host__ __device__ __forceinline__ bool df_segment(int wg, int nwg, int seg, int pairs, int SP, int q, long& item, DfSeg& o) {
+  if (q == 0) {
+    const long items = (long)pairs * SP;
+    if (seg == 0) item = items * wg / nwg;
+    const long item_end = items * (wg + 1) / nwg;
+    if (item >= item_end) return false;
+    o.pair = (int)(item / SP);
+    o.t0 = (int)(item - (long)o.pair * SP);
+    const long left = item_end - item;
+    o.n = (long)(SP - o.t0) < left ? SP - o.t0 : (int)left;
+    item += o.n;
+    return true;
+  }
+  const int k = SP / q, r = SP - k * q;
+  if (wg < pairs * k) {
+    if (seg) return false;
+    o.pair = wg / k;
+    o.t0 = (wg - o.pair * k) * q;
+    o.n = q;
+    return true;
+  }
+  if (r == 0) return false;
+  const int m = q / r > 1 ? q / r : 1;
+  const int p = (wg - pairs * k) * m + seg;
+  if (seg >= m || p >= pairs) return false;
+  o.pair = p;
+  o.t0 = k * q;
+  o.n = r;
+  return true;
+}
+
 struct DfArgs {
   const float* x;                     // [S*B][x_ctot] fp32: the layer's input rows
   int x_ctot;
@@ -1777,6 +1818,7 @@ struct DfArgs {
   float* slabv;                       // LRT: partial variances sigma^2 . x^2 (same layout)
   long slab_stride;
   int S, B, nchunk, nrs, rows_per_wg;
+  int q;                              // item schedule (df_segment)
 };
 
 template <int EM>
@@ -1787,18 +1829,13 @@ __global__ __launch_bounds__(TF_THREADS) void densef_fwd_kernel(const DfArgs A) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = wave & 3, mh = wave >> 2;
   build_sign_lut_f32((uint4*)(smem + FDF_O_LUT), tid);
-  // Work items = (particle, chunk, 32-row step), numbered pair-major; workgroup g takes the contiguous items
-  // [items g / G, items (g + 1) / G): every CU gets the same number of row steps whatever S * nchunk is (100 pairs x 2 row
-  // ranges used to leave 56 of 256 CUs idle).  A range that crosses a pair boundary reloads the weight fragments once.
+  // this workgroup's (pair, row step range) segments: df_segment (100 pairs x 2 row ranges used to leave 56 of 256 CUs idle)
   const int SP = (A.B + FDF_ROWS - 1) / FDF_ROWS;
-  const long items = (long)A.S * A.nchunk * SP;
-  const long wg = xcd_contiguous_id(blockIdx.x, gridDim.x);   // neighbours in item space (the same weight fragments) share an L2
-  long item = items * wg / gridDim.x;
-  const long item_end = items * (wg + 1) / gridDim.x;
-  while (item < item_end) {
-  const int pair = (int)(item / SP), t_first = (int)(item - (long)pair * SP);
-  const int nsteps = (int)min((long)(SP - t_first), item_end - item);
-  item += nsteps;
+  const int wg = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);   // neighbours in item space (the same weight fragments) share an L2
+  long item = 0;
+  DfSeg sg_;
+  for (int seg = 0; df_segment(wg, (int)gridDim.x, seg, A.S * A.nchunk, SP, A.q, item, sg_); ++seg) {
+  const int pair = sg_.pair, t_first = sg_.t0, nsteps = sg_.n;
   const int s = pair / A.nchunk, chunk = pair - s * A.nchunk;
   const int b0 = t_first * FDF_ROWS, b1 = min(A.B, b0 + nsteps * FDF_ROWS);
   const int ch0 = chunk * FDF_CH;
@@ -1953,6 +1990,7 @@ struct DfBwdArgs {
   long gw_stride; int gb_stride;
   int KP;
   int S, B, nchunk, nrs, rows_per_wg;
+  int q;                                // item schedule of the dX launch (df_segment)
 };
 
 enum {
@@ -2012,16 +2050,13 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dx_kernel(const DfBwdArgs A
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c0t = wave & 3, mh = wave >> 2;   // c-tiles c0t, c0t + 4, c0t + 8, c0t + 12 (< 15); row half
   build_sign_lut_f32((uint4*)(smem + FDX_O_LUT), tid);
-  // balanced (particle, chunk, row step) item ranges: see densef_fwd_kernel
+  // this workgroup's (pair, row step range) segments: df_segment
   const int SP = (A.B + FDF_ROWS - 1) / FDF_ROWS;
-  const long items = (long)A.S * A.nchunk * SP;
-  const long wg = xcd_contiguous_id(blockIdx.x, gridDim.x);   // neighbours in item space (the same weight fragments) share an L2
-  long item = items * wg / gridDim.x;
-  const long item_end = items * (wg + 1) / gridDim.x;
-  while (item < item_end) {
-  const int pair = (int)(item / SP), t_first = (int)(item - (long)pair * SP);
-  const int nsteps = (int)min((long)(SP - t_first), item_end - item);
-  item += nsteps;
+  const int wg = (int)xcd_contiguous_id(blockIdx.x, gridDim.x);
+  long item = 0;
+  DfSeg sg_;
+  for (int seg = 0; df_segment(wg, (int)gridDim.x, seg, A.S * A.nchunk, SP, A.q, item, sg_); ++seg) {
+  const int pair = sg_.pair, t_first = sg_.t0, nsteps = sg_.n;
   const int s = pair / A.nchunk, chunk = pair - s * A.nchunk;
   const int b0 = t_first * FDF_ROWS, b1 = min(A.B, b0 + nsteps * FDF_ROWS);
   const int ch0 = chunk * FDF_CH, w0 = ch0 >> 5;

@@ -1800,10 +1800,52 @@ static void densef_geometry(const GroupArgs& A, int nchunk, int max_rs, int* nrs
   *rows_per_wg = ((steps + r - 1) / r) * FDF_ROWS;
 }
 
-// forward / dX of the wide dense layer: one workgroup per CU, each a contiguous range of (particle, chunk, 32-row step) items
-static unsigned densef_balanced_grid(const GroupArgs& A, int nchunk) {
-  const long items = (long)A.cg.S * nchunk * ((A.cg.B + FDF_ROWS - 1) / FDF_ROWS);
-  return (unsigned)std::max(1L, std::min(items, 256L));
+// forward / dX of the wide dense layer: how the (particle, chunk, 32-row step) items are dealt to at most 256 workgroups
+// (df_segment in kernels_f32.h).  *q = 0: equal contiguous item ranges (most workgroups load weight fragments twice); *q > 0:
+// full ranges of q steps inside a pair + packed remainders.  Cost model: a row step ~5 us, a fragment load ~7 us (measured).
+static unsigned densef_schedule(const GroupArgs& A, int nchunk, int* q) {
+  const int SP = (A.cg.B + FDF_ROWS - 1) / FDF_ROWS, pairs = A.cg.S * nchunk;
+  const long items = (long)pairs * SP;
+  const unsigned gbal = (unsigned)std::max(1L, std::min(items, 256L));
+  const double c = 5.0, P = 7.0;
+  const long per = (items + gbal - 1) / gbal;
+  const double cost_bal = per * c + (per >= SP ? (double)((per + SP - 1) / SP + 1) : 2.0) * P;
+  *q = 0;
+  unsigned best = gbal;
+  double best_cost = cost_bal;
+  for (int qq = (int)std::max(1L, (items + 255) / 256); qq <= SP; ++qq) {
+    const int k = SP / qq, r = SP - k * qq, m = r ? std::max(1, qq / r) : 0;
+    const long G = (long)pairs * k + (r ? (pairs + m - 1) / m : 0);
+    if (G > 256) continue;
+    const double cost = std::max(k ? qq * c + P : 0.0, r ? m * (r * c + P) : 0.0);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = (unsigned)G;
+      *q = qq;
+    }
+    if (k == 1 && r == 0) break;
+  }
+  return best;
+}
+
+// host-side check of a schedule (dry-run validation): every (pair, row step) item dealt exactly once
+static int densef_check_schedule(const GroupArgs& A, int nchunk, unsigned grid, int q) {
+  const int SP = (A.cg.B + FDF_ROWS - 1) / FDF_ROWS, pairs = A.cg.S * nchunk;
+  std::vector<unsigned char> seen((size_t)pairs * SP, 0);
+  for (unsigned wg = 0; wg < grid; ++wg) {
+    long item = 0;
+    DfSeg sg;
+    for (int seg = 0; df_segment((int)wg, (int)grid, seg, pairs, SP, q, item, sg); ++seg) {
+      if (sg.pair < 0 || sg.pair >= pairs || sg.t0 < 0 || sg.n < 1 || sg.t0 + sg.n > SP)
+        return fail(BNN_E_INVALID, "internal: dense item schedule out of range (S %d B %d q %d)", A.cg.S, A.cg.B, q);
+      for (int t = sg.t0; t < sg.t0 + sg.n; ++t)
+        if (seen[(size_t)sg.pair * SP + t]++) return fail(BNN_E_INVALID, "internal: dense item schedule deals an item twice (S %d B %d q %d)", A.cg.S, A.cg.B, q);
+      if (seg > 4096) return fail(BNN_E_INVALID, "internal: dense item schedule does not terminate");
+    }
+  }
+  for (unsigned char v : seen)
+    if (!v) return fail(BNN_E_INVALID, "internal: dense item schedule leaves an item out (S %d B %d q %d)", A.cg.S, A.cg.B, q);
+  return 0;
 }
 
 static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t st, Prof* pf, int gi, bool fuse_last, const BnnDropout* drop, bool train) {
@@ -1830,7 +1872,8 @@ static int launch_densef_fwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   F.B = A.cg.B;
   F.nchunk = ly.cin / FDF_CH;
   static_assert(FDF_LDS <= 160 * 1024 && FDX_LDS <= 160 * 1024 && DWF_LDS <= 160 * 1024, "LDS budgets");
-  const unsigned grid = densef_balanced_grid(A, F.nchunk);
+  const unsigned grid = densef_schedule(A, F.nchunk, &F.q);
+  if (g_dry) BNN_TRY(densef_check_schedule(A, F.nchunk, grid, F.q));
   ProfScope ps_(pf, PK_FWD, gi, st);
   ps_.name("densef_fwd_kernel<%d>", em);
   BNN_DRY_RETURN();
@@ -1993,7 +2036,8 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
     }
   }
   {
-    const unsigned grid = densef_balanced_grid(A, F.nchunk);
+    const unsigned grid = densef_schedule(A, F.nchunk, &F.q);
+    if (g_dry) BNN_TRY(densef_check_schedule(A, F.nchunk, grid, F.q));
     ProfScope ps_(pf, PK_DX, gi, st);
     ps_.name("densef_dx_kernel<%d>", em);
     if (!g_dry) {

@@ -17,6 +17,10 @@ def lib():
 
 
 GEOMS = [(1, 1), (1, 33), (1, 100), (2, 7), (2, 257), (10, 1000), (20, 1000), (3, 33)]
+# the fp32 dense forward / dX deal (particle, chunk, row step) items to <= 256 workgroups (equal ranges or full ranges + packed
+# remainders): validation enumerates every workgroup's segments on the host and refuses a schedule that drops or repeats an item
+DENSE_GEOMS = [(1, 1000), (2, 100), (3, 500), (5, 250), (7, 333), (10, 100), (10, 250), (10, 500), (12, 1000), (13, 999),
+               (16, 640), (25, 1000), (26, 64), (40, 1000), (64, 32), (100, 10)]
 
 
 @pytest.mark.parametrize("net,prec", [("inception", N.PREC_BF16X3), ("inception", N.PREC_F32), ("linear", N.PREC_BF16X3),
@@ -81,3 +85,16 @@ def test_more_than_256_particles_keep_their_dw_slabs_apart(lib, prec):
             assert ws.value > 0
         finally:
             lib.bnn_plan_destroy(p)
+
+
+def test_fp32_dense_item_schedules_cover_every_item_once(lib):
+    for S, B in GEOMS + DENSE_GEOMS:
+        for mode in (N.MODE_FLIPOUT, N.MODE_LRT, N.MODE_RADIAL):
+            d = N.PlanDesc(0, mode, N.PREC_F32, S, B, 30, 18, 0)
+            p = C.c_void_p()
+            N.check(lib.bnn_plan_create(C.byref(d), C.byref(p)))
+            try:
+                for train in (1, 0):
+                    assert lib.bnn_plan_validate(p, -1, S, B, train) == 0, (S, B, mode, train, lib.bnn_last_error())
+            finally:
+                lib.bnn_plan_destroy(p)
