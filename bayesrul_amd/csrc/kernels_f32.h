@@ -1991,6 +1991,7 @@ struct DfBwdArgs {
   int KP;
   int S, B, nchunk, nrs, rows_per_wg;
   int q;                                // item schedule of the dX launch (df_segment)
+  int q_dw;                             // steps per full row range of the dW launch (df_segment with q > 0)
 };
 
 enum {
@@ -2176,18 +2177,22 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
   const int tid = threadIdx.x, lane = tid & 63, i16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = wave & 3, cpar = wave >> 2;   // c-tiles cpar, cpar + 2, ... (< 15)
-  int bid = blockIdx.x;
-  const int rs = bid % A.nrs;
-  bid /= A.nrs;
-  const int chunk = bid % A.nchunk, s = bid / A.nchunk;
-  if (s >= A.S) return;
-  const int b0 = rs * A.rows_per_wg, b1 = min(A.B, b0 + A.rows_per_wg);
-  const int nsteps = (b1 - b0 + FDF_ROWS - 1) / FDF_ROWS;
-  const int ch0 = chunk * FDF_CH, w0 = ch0 >> 5;
   {
     uint32_t* z = (uint32_t*)smem;
     for (int k = tid; k < DWF_LDS / 4; k += TF_THREADS) z[k] = 0u;
   }
+  // this workgroup's (pair, row step range) segments (df_segment, q > 0: full ranges of q steps + packed remainders): the
+  // range starting at step j q of its pair is the pair's row range j - range 0 stores the gradient image, the others partial
+  // images (dense_addn_kernel)
+  const int SP = (A.B + FDF_ROWS - 1) / FDF_ROWS;
+  long item_ = 0;
+  DfSeg sg_;
+  for (int seg = 0; df_segment((int)blockIdx.x, (int)gridDim.x, seg, A.S * A.nchunk, SP, A.q_dw, item_, sg_); ++seg) {
+  const int rs = sg_.t0 / A.q_dw;
+  const int s = sg_.pair / A.nchunk, chunk = sg_.pair - s * A.nchunk;
+  const int b0 = sg_.t0 * FDF_ROWS, b1 = min(A.B, b0 + sg_.n * FDF_ROWS);
+  const int nsteps = sg_.n;
+  const int ch0 = chunk * FDF_CH, w0 = ch0 >> 5;
   f32x4 acc_a[8], acc_b[TWO ? 8 : 1];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
@@ -2325,6 +2330,8 @@ __global__ __launch_bounds__(TF_THREADS) void densef_dw_kernel(const DfBwdArgs A
       tv += __shfl_xor(tv, 32, 64);
       if (g4 == 0) (rs == 0 ? A.gb_b : A.gb2_b)[(long)A.gb_stride * pimg + n] = tv;
     }
+  }
+  __syncthreads();   // the staging slots are reused by the next segment
   }
 }
 

@@ -1994,11 +1994,32 @@ static int launch_densef_bwd(BnnPlan* p, const GroupArgs& A, int em, hipStream_t
   F.nchunk = ly.cin / FDF_CH;
   if (br.dx_t < 0 || A.t[br.dx_t].ctot != F.x_ctot) return fail(BNN_E_INVALID, "fp32 dense backward: gradient tensor shape");
   {
-    // dW: up to 8 row ranges per (particle, chunk), every range but the first into a partial image of its own; (nrs - 1) * S
-    // <= 25 partial images exist in the workspace (nrs <= 256 / (S * nchunk))
-    densef_geometry(A, F.nchunk, 8, &F.nrs, &F.rows_per_wg);
-    if ((long)(F.nrs - 1) * F.S > DENSEF_DW_PARTS) return fail(BNN_E_INVALID, "internal: dense dW partial images");
-    const unsigned grid = (unsigned)(F.S * F.nchunk * F.nrs);
+    // dW: a (particle, chunk) pair's row steps are cut into full ranges of q steps (one workgroup each) + a remainder (packed
+    // m pairs to a workgroup): up to 8 ranges per pair, every range but the first into a partial image of its own; (ranges - 1)
+    // * S <= 25 partial images exist in the workspace.  The cheapest admissible q by a small cost model:
+    unsigned grid = 0;
+    {
+      const int SP = (F.B + FDF_ROWS - 1) / FDF_ROWS, pairs = F.S * F.nchunk;
+      double best = 1e30;
+      for (int qq = 1; qq <= SP; ++qq) {
+        const int k = SP / qq, r = SP - k * qq, m = r ? std::max(1, qq / r) : 0, ranges = k + (r ? 1 : 0);
+        const long G = (long)pairs * k + (r ? (pairs + m - 1) / m : 0);
+        if ((G > 256 && ranges > 1) || ranges > 8 || (long)(ranges - 1) * F.S > DENSEF_DW_PARTS) continue;   // (one range per pair always exists)
+        // measured: a row step 5.5 us with two contractions (Flipout, LRT), 2.6 us with one; 8 us per range for the zero fill,
+        // the first loads and the flush; 8 us for the add launch + 1.5 us per partial image it reads
+        const double cs = em == EM_PLAIN ? 2.6 : 5.5;
+        const double cost = (std::max(k ? qq * cs + 8.0 : 0.0, r ? m * (r * cs + 8.0) : 0.0) + (ranges > 1 ? 8.0 + (ranges - 1) * 1.5 : 0.0)) *
+                            (double)((G + 255) / 256);
+        if (cost < best) {
+          best = cost;
+          grid = (unsigned)G;
+          F.q_dw = qq;
+          F.nrs = ranges;
+        }
+      }
+      if (!grid) return fail(BNN_E_INVALID, "internal: no dense dW schedule for S %d B %d", F.S, F.B);
+      if (g_dry) BNN_TRY(densef_check_schedule(A, F.nchunk, grid, F.q_dw));
+    }
     ProfScope ps_(pf, PK_DW, gi, st);
     ps_.name("densef_dw_kernel<%d>", em);
     // the second row range's partial images: laid out like the gradient images (same layer offset and particle strides)
