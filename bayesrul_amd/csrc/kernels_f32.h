@@ -1381,6 +1381,10 @@ template <int KIND, bool LRT = false> __host__ __device__ constexpr int tw_xpitc
 __host__ __device__ constexpr int tw_xch(int l) { return l == 8 ? 64 : 0; }
 
 // one (layer, n-tile) job over the c-tiles [CT0, CT0 + NCT) of the layer's own input channels, all taps
+struct TwPre {
+  float bz[8], ax[8];
+};
+
 template <int EM, int KIND, int LY, int NT, int CT0, int NCT, bool BIAS>
 struct TwJob {
   static constexpr bool FO = (EM == EM_FLIPOUT), LRT = (EM == EM_LRT), TWO = FO || LRT;
@@ -1410,6 +1414,18 @@ struct TwJob {
     }
   }
 
+  // the operands a job needs before its first MFMA: the dz column fragments of its cout tile and the X fragments of its first
+  // tile.  The PREVIOUS job of the wave issues these reads in front of its last tile (tw_role), so that their LDS latency
+  // hides behind eight MFMAs instead of opening every job (measured: 9 + 12 us of the two launches)
+  __device__ __forceinline__ void preload(const char* sl, int lane, TwPre& q) const {
+    const int i16 = lane & 15, g4 = lane >> 4;
+    constexpr int n0 = tw_zch<KIND>(LY) + NT * 16;
+    const char* zi = sl + tw_zoff<KIND, LRT>(LY) + g4 * tw_zpitch<KIND>(LY) + (n0 + i16) * 4;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) q.bz[ks] = (TFV & 2048) ? 1.f + (float)lane : *(const float*)(zi + 4 * ks * tw_zpitch<KIND>(LY));   // (2048: diagnostics)
+    load_a(sl, 0, lane, q.ax);
+  }
+
   // acc_mean += T, acc_dW += (s_in (x) s_out) o T.  siw = the window's s_in words of this layer (registers), sobx = 15 where
   // this lane's cout has s_out = -1, else 0.  The sign masks are computed first: they do not depend on T, whose last MFMA
   // is still in flight when the fold starts (it rides in the shadow of the NEXT tile's MFMAs).
@@ -1432,14 +1448,15 @@ struct TwJob {
     acc_a[tt] += T;
   }
 
-  __device__ __forceinline__ void run(const char* sl, const uint32_t* sg, int lane) {
+  // q: this job's preloaded operands; next(): issues the next job's preload (called in front of the last tile)
+  template <class NX>
+  __device__ __forceinline__ void run(const char* sl, const uint32_t* sg, int lane, const TwPre& q, NX&& next) {
     __builtin_amdgcn_sched_barrier(0);
     const int i16 = lane & 15, g4 = lane >> 4;
     constexpr int n0 = tw_zch<KIND>(LY) + NT * 16;
-    const char* zi = sl + tw_zoff<KIND, LRT>(LY) + g4 * tw_zpitch<KIND>(LY) + (n0 + i16) * 4;
     float bz[8];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) bz[ks] = *(const float*)(zi + 4 * ks * tw_zpitch<KIND>(LY));
+    for (int ks = 0; ks < 8; ++ks) bz[ks] = q.bz[ks];
     if constexpr (LRT) {
       // d mu = dLoc^T x, d sigma^2 = dVar^T x^2 (dLoc = dz, dVar = dz q): two contractions with their own operands on both
       // sides, chained straight into the accumulators (no sign fold)
@@ -1455,10 +1472,12 @@ struct TwJob {
         }
       }
       float axc[8], axn[8];
-      load_a(sl, 0, lane, axc);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) axc[ks] = q.ax[ks];
 #pragma unroll
       for (int tt = 0; tt < NTILE; ++tt) {
         if (tt + 1 < NTILE) load_a(sl, tt + 1, lane, axn);
+        else next();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
@@ -1475,8 +1494,9 @@ struct TwJob {
     uint32_t siw[4] = {0u, 0u, 0u, 0u}, sobx = 0;
     if constexpr (FO) {
 #pragma unroll
-      for (int w = 0; w < tf_cimg(LY) / 32; ++w) siw[w] = sg[LY * 8 + w];
-      sobx = ((sg[LY * 8 + 4 + ((NT * 16) >> 5)] >> (((NT * 16) & 31) + i16)) & 1u) ? 15u : 0u;   // s_out of this lane's column (cout)
+      for (int w = 0; w < tf_cimg(LY) / 32; ++w) siw[w] = (TFV & 2048) ? (uint32_t)lane * 0x9e3779b9u : sg[LY * 8 + w];
+      sobx = (TFV & 2048) ? (lane & 1 ? 15u : 0u)
+                          : (((sg[LY * 8 + 4 + ((NT * 16) >> 5)] >> (((NT * 16) & 31) + i16)) & 1u) ? 15u : 0u);   // s_out of this lane's column (cout)
     }
     if constexpr (BIAS) {
 #pragma unroll
@@ -1487,10 +1507,12 @@ struct TwJob {
     // structure in lockstep, so a fold phase between the MFMA phases would leave the matrix pipe idle in both.
     float axc[8], axn[8];
     f32x4 Tp = {0.f, 0.f, 0.f, 0.f};
-    load_a(sl, 0, lane, axc);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) axc[ks] = q.ax[ks];
 #pragma unroll
     for (int tt = 0; tt < NTILE; ++tt) {
       if (tt + 1 < NTILE) load_a(sl, tt + 1, lane, axn);
+      else next();   // the next job's first operands, behind this job's last eight MFMAs
       __builtin_amdgcn_sched_barrier(0);
       f32x4 T = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1541,7 +1563,9 @@ struct TwJob {
 
 struct TwNone {
   __device__ __forceinline__ void init() {}
-  __device__ __forceinline__ void run(const char*, const uint32_t*, int) {}
+  __device__ __forceinline__ void preload(const char*, int, TwPre&) const {}
+  template <class NX>
+  __device__ __forceinline__ void run(const char*, const uint32_t*, int, const TwPre&, NX&&) {}
   __device__ __forceinline__ void flush(const TfDwArgs&, int, int) const {}
 };
 
@@ -1657,9 +1681,22 @@ __device__ __forceinline__ void tw_role(const TfDwArgs& A, char* smem, const TwS
     if (ka < nwin && !(TFV & 4)) ld.issue(ka, lds0 + (ka % NS) * SLOT, sgb0 + (ka % NS) * 320);
     const char* sl = smem + (t % NS) * SLOT;
     const uint32_t* sg = sgb + (t % NS) * 80;
-    j0.run(sl, sg, lane);
-    j1.run(sl, sg, lane);
-    j2.run(sl, sg, lane);
+    TwPre q0, q1, q2;
+    j0.preload(sl, lane, q0);
+    if constexpr (KIND == 0) {
+      // each job issues its successor's first operand reads in front of its own last tile
+      j0.run(sl, sg, lane, q0, [&]() __attribute__((always_inline)) { j1.preload(sl, lane, q1); });
+      j1.run(sl, sg, lane, q1, [&]() __attribute__((always_inline)) { j2.preload(sl, lane, q2); });
+      j2.run(sl, sg, lane, q2, []() {});
+    } else {
+      // (the 1x1 kind is at 235 registers and its pooled layer's operands are three reads + two v_max each: chaining
+      // measured slower there - 181 instead of 178 us)
+      j0.run(sl, sg, lane, q0, []() {});
+      j1.preload(sl, lane, q1);
+      j1.run(sl, sg, lane, q1, []() {});
+      j2.preload(sl, lane, q2);
+      j2.run(sl, sg, lane, q2, []() {});
+    }
     // window t + 1 must have landed before the barrier: only the DMAs of later windows may stay in flight
     if (AHEAD == 2 && t + 2 < nwin) BNN_WAIT_VMCNT_WIDE(nper);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
